@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the reference's OWN Python on our parsed maps.
+
+Runs only in the build container (needs ``/root/reference``); the GPU box and the
+test-suite consume the committed ``tests/golden/*.npz`` / ``*.json`` outputs.
+
+How the reference is driven:
+
+* ``smarts`` is imported from ``/root/reference`` through a namespace shim
+  (``smarts/__init__.py`` insists on an installed distribution), with
+  ``sys.dont_write_bytecode`` so nothing is written into the read-only tree.
+* Third-party modules that are absent here (``sumolib``, ``shapely``, ``trimesh``,
+  ``pybullet`` …) are replaced by *name-only* stub modules so that the
+  reference's modules import.  The only stubbed *functions* that are ever
+  called are ``sumolib.geomhelper.positionAtShapeOffset`` /
+  ``polygonOffsetWithMinimumDistanceToPoint`` / ``distance``, which delegate to
+  the reference's own in-tree twins (``smarts/core/utils/math.py:293-390``), and
+  ``pybullet.getQuaternionFromEuler`` (closed-form, for lidar rays).
+* The reference's ``SumoRoadNetwork`` is instantiated around our parsed
+  network object (``smarts_amd.sumo_map.SumoNet`` exposes the sumolib accessor
+  names), so ``LanePoints.from_sumo``, ``waypoint_paths``,
+  ``_equally_spaced_path``, ``nearest_lanes`` etc. are the reference's code.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+"""
+import importlib
+import importlib.machinery
+import json
+import logging
+import math
+import os
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.environ.get("SMARTS_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+
+import numpy as np  # noqa: E402
+
+
+class _Anything:
+    """Attribute sink used for names that are imported but never executed."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    m.__getattr__ = lambda n: _Anything  # type: ignore
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], child, m)
+    return m
+
+
+def install_reference():
+    smarts = types.ModuleType("smarts")
+    smarts.__path__ = [os.path.join(REF, "smarts")]
+    smarts.__spec__ = importlib.machinery.ModuleSpec("smarts", None, is_package=True)
+    sys.modules["smarts"] = smarts
+    sys.path.insert(0, REF)  # for `envision`
+
+    import functools
+
+    _stub("cached_property", cached_property=functools.cached_property)
+    for name in [
+        "shapely", "shapely.geometry", "shapely.geometry.base", "shapely.affinity", "shapely.ops",
+        "trimesh", "trimesh.scene", "trimesh.exchange", "trimesh.exchange.gltf", "trimesh.visual",
+        "sh", "yattag", "tableprint", "websocket", "rtree", "gym", "gym.spaces",
+        "pybullet_utils", "pybullet_utils.bullet_client",
+        "sumolib", "sumolib.net", "sumolib.net.edge", "sumolib.net.lane", "sumolib.geomhelper",
+        "sumo", "sumo.tools", "sumo.tools.sumolib", "sumo.tools.traci",
+        "traci", "traci.constants", "traci.exceptions",
+    ]:
+        _stub(name)
+
+    def _quat_from_euler(rpy):
+        # pybullet.getQuaternionFromEuler (x, y, z, w), ZYX convention
+        r, p, y = rpy
+        cr, sr = math.cos(r * 0.5), math.sin(r * 0.5)
+        cp, sp = math.cos(p * 0.5), math.sin(p * 0.5)
+        cy, sy = math.cos(y * 0.5), math.sin(y * 0.5)
+        return (
+            sr * cp * cy - cr * sp * sy,
+            cr * sp * cy + sr * cp * sy,
+            cr * cp * sy - sr * sp * cy,
+            cr * cp * cy + sr * sp * sy,
+        )
+
+    _stub("pybullet", getQuaternionFromEuler=_quat_from_euler, MAX_RAY_INTERSECTION_BATCH_SIZE=16384,
+          DIRECT=2, TORQUE_CONTROL=1, POSITION_CONTROL=2)
+
+    sys.modules["sumo"].SUMO_HOME = "/nonexistent-sumo-home"
+    sys.modules["sumo.tools"].traci = sys.modules["sumo.tools.traci"]
+    rmath = importlib.import_module("smarts.core.utils.math")
+    gh = sys.modules["sumolib.geomhelper"]
+    gh.positionAtShapeOffset = rmath.position_at_shape_offset
+    gh.distance = rmath.euclidean_distance
+    gh.polygonOffsetWithMinimumDistanceToPoint = (
+        lambda point, shape, perpendicular=False: rmath.polygon_offset_with_minimum_distance_to_point(point, shape)
+    )
+    gh.distancePointToPolygon = rmath.distance_point_to_polygon
+    sys.modules["sumolib"].geomhelper = gh
+    sys.modules["sumo.tools.sumolib"].geomhelper = gh
+    sys.modules["sumo.tools"].sumolib = sys.modules["sumolib"]
+    return rmath
+
+
+def make_reference_road_network(net, spacing=1.0):
+    """The reference's SumoRoadNetwork around our parsed net (no sumolib)."""
+    from smarts.core.lanepoints import LanePoints
+    from smarts.core.sumo_road_network import SumoRoadNetwork
+
+    # sumolib.Net API used by the reference that is not a plain accessor
+    def getNeighboringLanes(x, y, r=0.1, includeJunctions=True, allowFallback=True):
+        return net.neighboring_lanes(x, y, r, includeJunctions)
+
+    net.getNeighboringLanes = getNeighboringLanes
+
+    rn = SumoRoadNetwork.__new__(SumoRoadNetwork)
+    rn._log = logging.getLogger("ref")
+    rn._graph = net
+    rn._net_file = net.source
+    rn._map_spec = types.SimpleNamespace(lanepoint_spacing=spacing, default_lane_width=None,
+                                         shift_to_origin=True, source=net.source)
+    rn._default_lane_width = 3.2
+    rn._surfaces = {}
+    rn._lanes = {}
+    rn._roads = {}
+    rn._waypoints_cache = SumoRoadNetwork._WaypointsCache()
+    rn._lanepoints = LanePoints.from_sumo(rn, spacing=spacing)
+    return rn
+
+
+def dump_lanepoints(rn):
+    lps = rn._lanepoints._linked_lanepoints
+    index = {id(l): i for i, l in enumerate(lps)}
+    lanes = sorted({l.lp.lane.lane_id for l in lps})
+    lane_no = {lid: i for i, lid in enumerate(lanes)}
+    nxt_off = [0]
+    nxt = []
+    for l in lps:
+        nxt += [index[id(n)] for n in l.nexts]
+        nxt_off.append(len(nxt))
+    return dict(
+        x=np.array([l.lp.pose.position[0] for l in lps]),
+        y=np.array([l.lp.pose.position[1] for l in lps]),
+        heading=np.array([float(l.lp.pose.heading) for l in lps]),
+        inferred=np.array([l.is_inferred for l in lps], dtype=np.uint8),
+        lane=np.array([lane_no[l.lp.lane.lane_id] for l in lps], dtype=np.int32),
+        lane_ids=np.array(lanes),
+        next_off=np.array(nxt_off, dtype=np.int32),
+        next_idx=np.array(nxt, dtype=np.int32),
+    )
+
+
+def sample_poses(net, rng, n, lateral=2.5, heading_noise=0.6, far_fraction=0.05):
+    """Random poses near lanes (plus a few far off-road ones)."""
+    from smarts_amd.sumo_map import polyline_point_at
+
+    lanes = net.all_lanes()
+    poses = []
+    for i in range(n):
+        lane = lanes[rng.integers(len(lanes))]
+        shape = np.asarray(lane.shape, dtype=np.float64)
+        seg = np.sqrt(((shape[1:] - shape[:-1]) ** 2).sum(axis=1))
+        total = float(seg.sum())
+        s = rng.uniform(0.0, total)
+        x, y = polyline_point_at(shape, s)
+        x2, y2 = polyline_point_at(shape, min(s + 0.5, total))
+        if (x2, y2) == (x, y):
+            x0, y0 = polyline_point_at(shape, max(s - 0.5, 0.0))
+            dxv, dyv = x - x0, y - y0
+        else:
+            dxv, dyv = x2 - x, y2 - y
+        h = math.atan2(dyv, dxv) - math.pi / 2
+        lat = rng.normal(0.0, lateral / 2.5)
+        if rng.random() < far_fraction:
+            lat = rng.uniform(-30, 30)
+        x += -math.sin(h + math.pi / 2) * lat
+        y += math.cos(h + math.pi / 2) * lat
+        h += rng.normal(0.0, heading_noise) if rng.random() < 0.8 else rng.uniform(-math.pi, math.pi)
+        h = (h + math.pi) % (2 * math.pi) - math.pi
+        poses.append((float(x), float(y), float(h)))
+    return poses
+
+
+def dump_waypoint_paths(rn, poses, lookahead, route_kind):
+    """Run the reference's waypoint_paths for every pose; flatten the ragged result."""
+    from smarts.core.coordinates import Heading, Pose
+    from smarts.core.utils.math import fast_quaternion_from_angle
+
+    lane_ids = sorted(l.getID() for l in rn._graph.all_lanes())
+    lane_no = {lid: i for i, lid in enumerate(lane_ids)}
+    rec = dict(path_off=[0], wp_off=[0], x=[], y=[], heading=[], lane=[], lane_index=[], width=[], speed=[])
+    for (x, y, h) in poses:
+        pose = Pose(position=np.array([x, y, 0.0]), orientation=fast_quaternion_from_angle(Heading(h)),
+                    heading_=Heading(h))
+        route = rn.empty_route() if route_kind == "empty_route" else None
+        paths = rn.waypoint_paths(pose, lookahead=lookahead, route=route)
+        for p in paths:
+            for wp in p:
+                rec["x"].append(float(wp.pos[0]))
+                rec["y"].append(float(wp.pos[1]))
+                rec["heading"].append(float(wp.heading))
+                rec["lane"].append(lane_no[wp.lane_id])
+                rec["lane_index"].append(int(wp.lane_index))
+                rec["width"].append(float(wp.lane_width))
+                rec["speed"].append(float(wp.speed_limit))
+            rec["wp_off"].append(len(rec["x"]))
+        rec["path_off"].append(len(rec["wp_off"]) - 1)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["lane_ids"] = np.array(lane_ids)
+    out["poses"] = np.array(poses)
+    out["lookahead"] = np.array(lookahead)
+    return out
+
+
+def dump_nearest(rn, poses):
+    from smarts.core.coordinates import Point
+
+    lane_ids = sorted(l.getID() for l in rn._graph.all_lanes())
+    lane_no = {lid: i for i, lid in enumerate(lane_ids)}
+    nearest = []
+    dist = []
+    on_road = []
+    for (x, y, h) in poses:
+        pt = Point(x, y, 0.0)
+        nl = rn.nearest_lanes(pt)
+        nearest.append(lane_no[nl[0][0].lane_id] if nl else -1)
+        dist.append(nl[0][1] if nl else -1.0)
+        on_road.append(rn.road_with_point(pt) is not None)
+    return dict(poses=np.array(poses), nearest=np.array(nearest, dtype=np.int32), dist=np.array(dist),
+                on_road=np.array(on_road, dtype=np.uint8), lane_ids=np.array(lane_ids))
+
+
+SCENARIOS = {
+    "loop": "scenarios/loop",
+    "4lane": "scenarios/intersections/4lane",
+    "minicity": "scenarios/minicity",
+}
+
+
+def main():
+    install_reference()
+    from smarts_amd.sumo_map import load_net
+
+    logging.basicConfig(level=logging.WARNING)
+    for name, rel in SCENARIOS.items():
+        net = load_net(os.path.join(REF, rel))
+        rn = make_reference_road_network(net)
+        lp = dump_lanepoints(rn)
+        print(name, "lanepoints:", len(lp["x"]))
+        if name == "minicity":
+            # the full table is large; keep a digest + a slice
+            keep = 4000
+            digest = {k: (float(np.sum(v.astype(np.float64))) if v.dtype.kind in "fiu" else None) for k, v in lp.items()}
+            lp_small = {k: (v[:keep] if k not in ("lane_ids", "next_off", "next_idx") else v) for k, v in lp.items()}
+            lp_small["next_off"] = lp["next_off"][: keep + 1]
+            lp_small["next_idx"] = lp["next_idx"][: lp["next_off"][keep]]
+            lp_small["total"] = np.array(len(lp["x"]))
+            lp_small["sum_x"] = np.array(digest["x"])
+            lp_small["sum_y"] = np.array(digest["y"])
+            lp_small["sum_heading"] = np.array(digest["heading"])
+            np.savez_compressed(os.path.join(OUT, f"lanepoints_{name}.npz"), **lp_small)
+        else:
+            np.savez_compressed(os.path.join(OUT, f"lanepoints_{name}.npz"), **lp)
+        rng = np.random.default_rng(20240 + len(name))
+        n = 300 if name != "minicity" else 200
+        poses = sample_poses(net, rng, n)
+        for lookahead in (16, 32):
+            for route_kind in ("empty_route", "none"):
+                if route_kind == "none" and lookahead == 16:
+                    continue
+                wp = dump_waypoint_paths(rn, poses, lookahead, route_kind)
+                np.savez_compressed(os.path.join(OUT, f"waypoints_{name}_{route_kind}_{lookahead}.npz"), **wp)
+                print(name, route_kind, lookahead, "paths:", len(wp["wp_off"]) - 1)
+        nr = dump_nearest(rn, poses)
+        np.savez_compressed(os.path.join(OUT, f"nearest_{name}.npz"), **nr)
+
+
+if __name__ == "__main__":
+    main()
