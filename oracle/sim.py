@@ -1,0 +1,353 @@
+"""Oracle: one environment instance, ticked the way ``SMARTS._step`` does (test infrastructure).
+
+Restates, per agent and sequentially:
+
+* the tick order of ``SMARTS._step`` (``smarts/core/smarts.py:236-327``): clock →
+  agent actions/controllers → physics → collisions → sensors → observe → teardown;
+* ``Sensors.observe`` and the event logic (``smarts/core/sensors.py:238-594``);
+* ``TripMeterSensor`` / ``DrivenPathSensor`` / ``AccelerometerSensor``
+  (``sensors.py:830-947, 1046-1087``), reward/score (``agent_manager.py:233-234``);
+* ``SMARTS.neighborhood_vehicles_around_vehicle`` (``smarts.py:1191-1208``);
+* ``_process_collisions`` (``smarts.py:1270-1291``) over
+  ``_query_bullet_contact_points`` (``chassis.py:60-80``).  The pybullet AABB /
+  closest-point queries are substituted by 2-D oriented-box distance <= 0.05 m of
+  the chassis footprints (wheels lie inside the footprint); DESIGN.md "Substitutions".
+
+Agents are Ackermann vehicles with the Lane action space, EndlessGoal missions and
+an empty route (what ``hiway-v0`` gives agents of a scenario without
+``missions.pkl``: ``scenario.py:289-290``, ``plan.py:225-249,321-323``).
+"""
+import math
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import controller as ctl
+from . import ref_math as rm
+from .dynamics import VehicleBody
+
+COLLISION_LEEWAY = 0.05  # chassis.py:75-78
+
+
+@dataclass
+class AgentConfig:
+    """The slice of ``AgentInterface`` this path reads (agent_interface.py:175-297)."""
+
+    waypoints_lookahead: Optional[int] = 32  # None = sensor disabled
+    neighborhood_radius: Optional[float] = None
+    neighborhood_enabled: bool = False
+    accelerometer: bool = True
+    max_episode_steps: Optional[int] = None
+    done_collision: bool = True
+    done_off_road: bool = True
+    done_off_route: bool = True
+    done_on_shoulder: bool = False
+    done_wrong_way: bool = False
+    done_not_moving: bool = False
+    not_moving_time: float = 60
+    not_moving_distance: float = 1
+
+
+class _Agent:
+    def __init__(self, body, cfg, road_map, sim):
+        self.body = body
+        self.cfg = cfg
+        self.alive = True
+        self.steps = 0
+        nl = road_map.nearest_lane(body.position)  # ControllerState.from_action_space (controllers/__init__.py:166-180)
+        self.ctrl = ctl.LaneFollowingControllerState(nl.lane_id if nl else None)
+        # TripMeterSensor.__init__ (sensors.py:885-898)
+        self.wps_for_distance = []
+        self.dist_travelled = 0.0
+        self.last_dist_travelled = 0.0
+        wps = road_map.waypoint_paths(body.position, body.heading, lookahead=1, within_radius=body.length)
+        if wps:
+            self.wps_for_distance.append(wps[0][0])
+        self.driven_path = deque(maxlen=500)  # sensors.py:838
+        self.linear_velocities = deque(maxlen=3)
+        self.angular_velocities = deque(maxlen=3)
+        self.collisions = []
+
+
+def _box_corners(x, y, heading, length, width):
+    f = (-math.sin(heading), math.cos(heading))
+    r = (math.cos(heading), math.sin(heading))
+    hl, hw = 0.5 * length, 0.5 * width
+    return [
+        (x + f[0] * hl + r[0] * hw, y + f[1] * hl + r[1] * hw),
+        (x + f[0] * hl - r[0] * hw, y + f[1] * hl - r[1] * hw),
+        (x - f[0] * hl - r[0] * hw, y - f[1] * hl - r[1] * hw),
+        (x - f[0] * hl + r[0] * hw, y - f[1] * hl + r[1] * hw),
+    ]
+
+
+def _seg_point_dist2(px, py, ax, ay, bx, by):
+    dx, dy = bx - ax, by - ay
+    ll = dx * dx + dy * dy
+    t = 0.0 if ll == 0.0 else ((px - ax) * dx + (py - ay) * dy) / ll
+    t = min(1.0, max(0.0, t))
+    ex, ey = ax + t * dx - px, ay + t * dy - py
+    return ex * ex + ey * ey
+
+
+def _point_in_box(px, py, x, y, heading, length, width):
+    f = (-math.sin(heading), math.cos(heading))
+    r = (math.cos(heading), math.sin(heading))
+    dx, dy = px - x, py - y
+    return abs(dx * f[0] + dy * f[1]) <= 0.5 * length and abs(dx * r[0] + dy * r[1]) <= 0.5 * width
+
+
+def boxes_within(a, b, leeway):
+    """True iff the 2-D distance between two oriented footprints is <= leeway.
+
+    Distance between convex polygons: 0 if they intersect, else attained between a
+    vertex of one and an edge of the other.
+    """
+    ca = _box_corners(a.x, a.y, a.heading, a.length, a.width)
+    cb = _box_corners(b.x, b.y, b.heading, b.length, b.width)
+    best = float("inf")
+    for P, Q, other in ((ca, cb, b), (cb, ca, a)):
+        for (px, py) in P:
+            if _point_in_box(px, py, other.x, other.y, other.heading, other.length, other.width):
+                return True
+            for k in range(4):
+                ax, ay = Q[k]
+                bx, by = Q[(k + 1) % 4]
+                best = min(best, _seg_point_dist2(px, py, ax, ay, bx, by))
+    if best <= leeway * leeway:
+        return True
+    # edge-edge crossings without any contained vertex (a "plus" configuration)
+    for i in range(4):
+        a0, a1 = ca[i], ca[(i + 1) % 4]
+        for k in range(4):
+            b0, b1 = cb[k], cb[(k + 1) % 4]
+            d1 = (a1[0] - a0[0]) * (b0[1] - a0[1]) - (a1[1] - a0[1]) * (b0[0] - a0[0])
+            d2 = (a1[0] - a0[0]) * (b1[1] - a0[1]) - (a1[1] - a0[1]) * (b1[0] - a0[0])
+            d3 = (b1[0] - b0[0]) * (a0[1] - b0[1]) - (b1[1] - b0[1]) * (a0[0] - b0[0])
+            d4 = (b1[0] - b0[0]) * (a1[1] - b0[1]) - (b1[1] - b0[1]) * (a1[0] - b0[0])
+            if (d1 > 0) != (d2 > 0) and (d3 > 0) != (d4 > 0):
+                return True
+    return False
+
+
+class OracleEnv:
+    """One SMARTS instance with N ego agents on one map."""
+
+    def __init__(self, road_map, spawns, configs, dt=0.1):
+        """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre)."""
+        self.road_map = road_map
+        self.dt = dt
+        self.elapsed_sim_time = 0.0
+        self.step_count = 0
+        self._round = rm.round_param_for_dt(dt)
+        self.agents = [
+            _Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(np.asarray(spawns, dtype=np.float64), configs)
+        ]
+
+    # ------------------------------------------------------------------ tick
+    def step(self, actions):
+        """``actions[i]`` is a Lane action name (or index into LANE_ACTION_NAMES) or None."""
+        rmap = self.road_map
+        self.elapsed_sim_time = round(self.elapsed_sim_time + self.dt, self._round)  # smarts.py:261-262
+        # 2. controllers (smarts.py:1233-1263)
+        for ag, action in zip(self.agents, actions):
+            if not ag.alive or action is None:
+                continue
+            if not isinstance(action, str):
+                action = ctl.LANE_ACTION_NAMES[int(action)]
+            target_speed, lane_change = ctl.LANE_ACTIONS[action]
+            thr, brk, steer = ctl.perform_lane_following(
+                rmap, ag.body, ag.ctrl, self.dt, target_speed=target_speed, lane_change=lane_change, route=()
+            )
+            ag.body.control(throttle=thr, brake=brk, steering=steer)
+        # physics (smarts.py:923-931)
+        for ag in self.agents:
+            if ag.alive:
+                ag.body.step(self.dt)
+        # collisions (smarts.py:1270-1291)
+        for i, ag in enumerate(self.agents):
+            ag.collisions = []
+            if not ag.alive:
+                continue
+            for j, other in enumerate(self.agents):
+                if j == i or not other.alive:
+                    continue
+                if boxes_within(ag.body, other.body, COLLISION_LEEWAY):
+                    ag.collisions.append(j)
+        # sensors + observe (smarts.py:287-301)
+        alive_states = [(j, a.body) for j, a in enumerate(self.agents) if a.alive]
+        obs, rewards, dones = {}, {}, {}
+        for i, ag in enumerate(self.agents):
+            if not ag.alive:
+                continue
+            ag.steps += 1  # SensorState.step (agent_manager.py:250-258)
+            o, done = self._observe(i, ag, alive_states)
+            obs[i] = o
+            dones[i] = done
+            rewards[i] = ag.dist_travelled - ag.last_dist_travelled  # agent_manager.py:233
+        for i, d in dones.items():  # smarts.py:314
+            if d:
+                self.agents[i].alive = False
+        self.step_count += 1
+        return obs, rewards, dones
+
+    # ------------------------------------------------------------------ observe
+    def _observe(self, i, ag, alive_states):
+        rmap, b, cfg = self.road_map, ag.body, ag.cfg
+        o = {}
+        # neighbourhood (sensors.py:241-266, smarts.py:1191-1208)
+        if cfg.neighborhood_enabled:
+            nvs = []
+            for j, ob in alive_states:
+                if j == i:
+                    continue
+                if cfg.neighborhood_radius is not None:
+                    d = np.linalg.norm(ob.position - b.position)
+                    if not d <= cfg.neighborhood_radius:
+                        continue
+                nv_lane = rmap.nearest_lane(ob.position, radius=b.length)
+                nvs.append(
+                    dict(
+                        slot=j,
+                        position=ob.position,
+                        box=(ob.length, ob.width, ob.height),
+                        heading=ob.heading,
+                        speed=ob.speed,
+                        lane_id=nv_lane.lane_id if nv_lane else None,
+                        road_id=nv_lane.road.road_id if nv_lane else None,
+                        lane_index=nv_lane.index if nv_lane else None,
+                    )
+                )
+            o["neighbors"] = nvs
+        # waypoints (sensors.py:268-275, 972-985)
+        if cfg.waypoints_lookahead is not None:
+            waypoint_paths = rmap.waypoint_paths(b.position, b.heading, lookahead=cfg.waypoints_lookahead, route=())
+        else:
+            waypoint_paths = rmap.waypoint_paths(b.position, b.heading, lookahead=1, within_radius=b.length)
+        closest_lane = rmap.nearest_lane(b.position)
+        lin_v, ang_v = b.linear_velocity, b.angular_velocity
+        o["ego"] = dict(
+            position=np.array(b.position),
+            box=(b.length, b.width, b.height),
+            heading=rm.wrap_heading(b.heading),
+            speed=b.speed,
+            steering=b.steering,
+            yaw_rate=b.yaw_rate,
+            lane_id=closest_lane.lane_id if closest_lane else None,
+            road_id=closest_lane.road.road_id if closest_lane else None,
+            lane_index=closest_lane.index if closest_lane else None,
+            linear_velocity=lin_v,
+            angular_velocity=ang_v,
+        )
+        if cfg.accelerometer:
+            o["ego"].update(self._accelerometer(ag, lin_v, ang_v))
+        # trip meter (sensors.py:349-351, 900-944)
+        if waypoint_paths:
+            self._append_waypoint_if_new(ag, waypoint_paths[0][0])
+        o["distance_travelled"] = ag.dist_travelled
+        ag.driven_path.append((self.elapsed_sim_time, b.position[:2]))  # sensors.py:842-847
+        o["waypoint_paths"] = waypoint_paths if cfg.waypoints_lookahead is not None else None
+        done, events = self._is_done_with_events(ag)
+        o["events"] = events
+        o["dt"] = self.dt
+        o["step_count"] = self.step_count
+        o["elapsed_sim_time"] = self.elapsed_sim_time
+        return o, done
+
+    def _accelerometer(self, ag, linear_velocity, angular_velocity):
+        """sensors.py:1053-1084."""
+        dt = self.dt
+        ag.linear_velocities.append(linear_velocity)
+        ag.angular_velocities.append(angular_velocity)
+        la = np.array((0.0, 0.0, 0.0))
+        aa = np.array((0.0, 0.0, 0.0))
+        lj = np.array((0.0, 0.0, 0.0))
+        aj = np.array((0.0, 0.0, 0.0))
+        if len(ag.linear_velocities) >= 2:
+            la = (ag.linear_velocities[-1] - ag.linear_velocities[-2]) / dt
+            if len(ag.linear_velocities) >= 3:
+                lj = la - (ag.linear_velocities[-2] - ag.linear_velocities[-3]) / dt
+        if len(ag.angular_velocities) >= 2:
+            aa = (ag.angular_velocities[-1] - ag.angular_velocities[-2]) / dt
+            if len(ag.angular_velocities) >= 3:
+                aj = aa - (ag.angular_velocities[-2] - ag.angular_velocities[-3]) / dt
+        return dict(linear_acceleration=la, angular_acceleration=aa, linear_jerk=lj, angular_jerk=aj)
+
+    def _append_waypoint_if_new(self, ag, new_wp):
+        """sensors.py:900-938 (endless mission: every waypoint counts)."""
+        ag.last_dist_travelled = ag.dist_travelled
+        if not ag.wps_for_distance:
+            ag.wps_for_distance.append(new_wp)
+            return
+        recent = ag.wps_for_distance[-1]
+        if np.linalg.norm(new_wp.pos - recent.pos) > 0.5:
+            heading_vec = rm.radians_to_vec(recent.heading)
+            disp_vec = new_wp.pos - recent.pos
+            direction = np.sign(np.dot(heading_vec, disp_vec))
+            ag.dist_travelled += direction * np.linalg.norm(disp_vec)
+            ag.wps_for_distance.append(new_wp)
+
+    # ------------------------------------------------------------------ events
+    def _is_done_with_events(self, ag):
+        """sensors.py:443-489."""
+        rmap, b, cfg = self.road_map, ag.body, ag.cfg
+        reached_goal = False  # EndlessGoal (plan.py:76-84)
+        collided = len(ag.collisions) > 0
+        is_off_road = not rmap.road_with_point(b.position)  # sensors.py:498-500
+        is_on_shoulder = False  # sensors.py:502-509
+        for corner in b.bounding_box:
+            if not rmap.road_with_point((corner[0], corner[1], 0)):
+                is_on_shoulder = True
+                break
+        is_not_moving = self._not_moving(ag)
+        reached_max = cfg.max_episode_steps is not None and ag.steps >= cfg.max_episode_steps
+        is_off_route, is_wrong_way = self._off_route_and_wrong_way(b)
+        done = (
+            (is_off_road and cfg.done_off_road)
+            or reached_goal
+            or reached_max
+            or (is_on_shoulder and cfg.done_on_shoulder)
+            or (collided and cfg.done_collision)
+            or (is_not_moving and cfg.done_not_moving)
+            or (is_off_route and cfg.done_off_route)
+            or (is_wrong_way and cfg.done_wrong_way)
+        )
+        events = dict(
+            collisions=list(ag.collisions),
+            off_road=is_off_road,
+            reached_goal=reached_goal,
+            reached_max_episode_steps=reached_max,
+            off_route=is_off_route,
+            on_shoulder=is_on_shoulder,
+            wrong_way=is_wrong_way,
+            not_moving=is_not_moving,
+            agents_alive_done=False,
+        )
+        return bool(done), events
+
+    def _not_moving(self, ag):
+        """sensors.py:511-525, 855-877."""
+        cfg = ag.cfg
+        if self.elapsed_sim_time < cfg.not_moving_time:
+            return False
+        threshold = self.elapsed_sim_time - cfg.not_moving_time
+        pts = [p for (t, p) in ag.driven_path if t >= threshold]
+        xs = np.array([p[0] for p in pts])
+        ys = np.array([p[1] for p in pts])
+        dist_array = (xs[:-1] - xs[1:]) ** 2 + (ys[:-1] - ys[1:]) ** 2
+        return bool(np.sum(np.sqrt(dist_array)) < cfg.not_moving_distance)
+
+    def _off_route_and_wrong_way(self, b):
+        """sensors.py:527-594 with an empty route."""
+        radius = np.linalg.norm((b.length, b.width)) * 0.5 + 5
+        nearest_lane = self.road_map.nearest_lane(b.position, radius=radius)
+        if not nearest_lane:
+            return (True, False)
+        if nearest_lane.in_junction:
+            is_wrong_way = False
+        else:
+            target_heading = nearest_lane.center_pose_heading_at_point(tuple(b.position))
+            is_wrong_way = bool(np.fabs(rm.heading_relative_to(b.heading, target_heading)) > 0.5 * np.pi)
+        return (False, is_wrong_way)  # no route roads => on route

@@ -61,7 +61,13 @@ def _stub(name, **attrs):
     m = types.ModuleType(name)
     m.__spec__ = importlib.machinery.ModuleSpec(name, None)
     m.__path__ = []
-    m.__getattr__ = lambda n: _Anything  # type: ignore
+
+    def _mod_getattr(n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Anything
+
+    m.__getattr__ = _mod_getattr  # type: ignore
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m
@@ -107,7 +113,10 @@ def install_reference():
         )
 
     _stub("pybullet", getQuaternionFromEuler=_quat_from_euler, MAX_RAY_INTERSECTION_BATCH_SIZE=16384,
-          DIRECT=2, TORQUE_CONTROL=1, POSITION_CONTROL=2)
+          DIRECT=2, GUI=1, TORQUE_CONTROL=1, POSITION_CONTROL=2, URDF_USE_IMPLICIT_CYLINDER=128,
+          URDF_ENABLE_CACHED_GRAPHICS_SHAPES=1024,
+          __all__=["getQuaternionFromEuler", "MAX_RAY_INTERSECTION_BATCH_SIZE", "DIRECT", "GUI", "TORQUE_CONTROL",
+                   "POSITION_CONTROL", "URDF_USE_IMPLICIT_CYLINDER", "URDF_ENABLE_CACHED_GRAPHICS_SHAPES"])
 
     sys.modules["sumo"].SUMO_HOME = "/nonexistent-sumo-home"
     sys.modules["sumo.tools"].traci = sys.modules["sumo.tools.traci"]
@@ -253,6 +262,98 @@ def dump_nearest(rn, poses):
                 on_road=np.array(on_road, dtype=np.uint8), lane_ids=np.array(lane_ids))
 
 
+def dump_controller(rn, net, rng, n):
+    """Reference LaneFollowingController.perform_lane_following on mock vehicles
+    (the reference's own tests drive sensors the same way: test_sensors.py:39-99)."""
+    from smarts.core.chassis import AckermannChassis
+    from smarts.core.controllers.lane_following_controller import (
+        LaneFollowingController,
+        LaneFollowingControllerState,
+    )
+    from smarts.core.coordinates import Heading, Point, Pose
+    from smarts.core.utils.math import fast_quaternion_from_angle
+
+    lane_ids = sorted(l.getID() for l in net.all_lanes())
+    lane_no = {lid: i for i, lid in enumerate(lane_ids)}
+    sim = types.SimpleNamespace(road_map=rn, last_dt=0.1, road_stiffness=100000.0)
+    sensor_state = types.SimpleNamespace(plan=types.SimpleNamespace(route=rn.empty_route(), road_map=rn))
+    poses = sample_poses(net, rng, n, lateral=1.5, heading_noise=0.15, far_fraction=0.0)
+    actions = [(15, 0), (0, 0), (12.5, 1), (12.5, -1)]
+    cols = {k: [] for k in [
+        "x", "y", "z", "heading", "speed", "lat_speed", "long_speed", "yaw_z", "target_speed", "lane_change",
+        "in_lat_int", "in_spd_int", "in_steer", "in_thr", "in_spd_err", "in_mcl_x", "in_mcl_y", "in_mcl_set",
+        "in_target_lane",
+        "throttle", "brake", "steering",
+        "out_lat_int", "out_spd_int", "out_steer", "out_thr", "out_spd_err", "out_mcl_x", "out_mcl_y", "out_mcl_set",
+        "out_hgain", "out_lgain", "out_target_lane",
+    ]}
+    for (x, y, h) in poses:
+        speed = float(rng.uniform(0.0, 22.0)) if rng.random() < 0.9 else 0.0
+        lat = float(rng.normal(0, 0.3))
+        yawz = float(rng.normal(0, 0.2))
+        z = 0.01265
+        ts, lc = actions[rng.integers(4)] if rng.random() < 0.7 else actions[0]
+        hd = Heading(h)
+        pose = Pose(position=np.array([x, y, z]), orientation=fast_quaternion_from_angle(hd), heading_=hd)
+        chassis = AckermannChassis.__new__(AckermannChassis)
+        lng = math.sqrt(max(speed * speed - lat * lat, 0.0))
+        chassis.__dict__["longitudinal_lateral_speed"] = (lng, lat)
+        chassis.__dict__["velocity_vectors"] = (np.array([lng, lat, 0.0]), np.array([0.0, 0.0, yawz]))
+        chassis.__dict__["mass_and_inertia"] = (2356.0, 2681.95008628)
+        captured = {}
+
+        def control(throttle=0, brake=0, steering=0, captured=captured):
+            captured.update(throttle=float(throttle), brake=float(brake), steering=float(steering))
+
+        vehicle = types.SimpleNamespace(
+            chassis=chassis, pose=pose, position=pose.position, heading=hd, speed=speed, length=3.68,
+            max_steering_wheel=12.56 / 17.4, control=control,
+        )
+        tl = rn.nearest_lane(Point(x, y, z))
+        st = LaneFollowingControllerState(tl.lane_id)
+        if rng.random() < 0.8:
+            st.lateral_integral_error = float(rng.normal(0, 0.2))
+            st.integral_speed_error = float(rng.normal(0, 2.0))
+            st.steering_state = float(np.clip(rng.normal(0, 0.3), -1, 1))
+            st.throttle_state = float(rng.uniform(0, 1))
+            st.speed_error = float(rng.normal(0, 1.0))
+        if rng.random() < 0.5:
+            st.min_curvature_location = (x + float(rng.normal(0, 2)), y + float(rng.normal(0, 2)))
+        rec_in = dict(
+            in_lat_int=st.lateral_integral_error, in_spd_int=st.integral_speed_error, in_steer=st.steering_state,
+            in_thr=st.throttle_state, in_spd_err=st.speed_error,
+            in_mcl_set=int(st.min_curvature_location != (None, None)),
+            in_mcl_x=st.min_curvature_location[0] or 0.0, in_mcl_y=st.min_curvature_location[1] or 0.0,
+            in_target_lane=lane_no[st.target_lane_id],
+        )
+        try:
+            LaneFollowingController.perform_lane_following(
+                sim, "a", vehicle, st, sensor_state, target_speed=ts, lane_change=lc)
+        except AssertionError:
+            continue
+        for k, v in rec_in.items():
+            cols[k].append(v)
+        for k, v in dict(x=x, y=y, z=z, heading=h, speed=speed, lat_speed=lat, long_speed=lng, yaw_z=yawz,
+                         target_speed=ts, lane_change=lc).items():
+            cols[k].append(v)
+        for k in ("throttle", "brake", "steering"):
+            cols[k].append(captured[k])
+        cols["out_lat_int"].append(float(st.lateral_integral_error))
+        cols["out_spd_int"].append(float(st.integral_speed_error))
+        cols["out_steer"].append(float(st.steering_state))
+        cols["out_thr"].append(float(st.throttle_state))
+        cols["out_spd_err"].append(float(st.speed_error))
+        cols["out_mcl_set"].append(int(st.min_curvature_location != (None, None)))
+        cols["out_mcl_x"].append(st.min_curvature_location[0] or 0.0)
+        cols["out_mcl_y"].append(st.min_curvature_location[1] or 0.0)
+        cols["out_hgain"].append(float(st.heading_error_gain))
+        cols["out_lgain"].append(float(st.lateral_error_gain))
+        cols["out_target_lane"].append(lane_no[st.target_lane_id])
+    out = {k: np.array(v) for k, v in cols.items()}
+    out["lane_ids"] = np.array(lane_ids)
+    return out
+
+
 SCENARIOS = {
     "loop": "scenarios/loop",
     "4lane": "scenarios/intersections/4lane",
@@ -296,6 +397,9 @@ def main():
                 print(name, route_kind, lookahead, "paths:", len(wp["wp_off"]) - 1)
         nr = dump_nearest(rn, poses)
         np.savez_compressed(os.path.join(OUT, f"nearest_{name}.npz"), **nr)
+        ct = dump_controller(rn, net, np.random.default_rng(777 + len(name)), 200 if name != "minicity" else 80)
+        np.savez_compressed(os.path.join(OUT, f"controller_{name}.npz"), **ct)
+        print(name, "controller cases:", len(ct["x"]))
 
 
 if __name__ == "__main__":
