@@ -1,0 +1,260 @@
+/*
+ * smx.h — C-ABI of libsmarts_mi355x.so: the MI355X-native SMARTS hot path.
+ *
+ * One handle = one GPU = one shard of E independent environment instances x N
+ * vehicle slots.  The boundary replaces the seam
+ *     SMARTS.step(agent_actions) -> (obs, rewards, dones, scores)
+ *                                   reference smarts/core/smarts.py:187-227, 236-327
+ *     SMARTS.reset(scenario)     -> first observations
+ *                                   reference smarts/core/smarts.py:365-460
+ * for a batch of instances, the way ParallelEnv batches whole processes
+ * (reference smarts/env/wrappers/parallel_env.py:214-233, 303-309 auto-reset).
+ * The reference has no FFI on this path (it imports pybullet/sumolib directly), so
+ * the entry points below are what a cffi/ctypes binding of that seam would bind;
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions: every function returns 0 on success, a negative smx_status on
+ * failure and never throws; smx_last_error() gives the text.  The caller owns
+ * every device buffer (PyTorch-ROCm tensors handed over as raw pointers); the
+ * library allocates only the map tables.  A handle is not thread-safe; distinct
+ * handles are independent.  smx_step / smx_reset enqueue work on the given HIP
+ * stream and do no host<->device copies and no synchronisation.
+ */
+#ifndef SMX_H
+#define SMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smx_handle_s* smx_handle;
+
+typedef enum smx_status {
+  SMX_OK = 0,
+  SMX_ERR_INVALID = -1,  /* bad argument / shape / null pointer */
+  SMX_ERR_HIP = -2,      /* a HIP runtime call failed */
+  SMX_ERR_STATE = -3,    /* call order (e.g. step before load_map) */
+  SMX_ERR_NOMEM = -4
+} smx_status;
+
+/* ---- action space: reference smarts/core/controllers/__init__.py:42-54, 137-144 ---- */
+enum {
+  SMX_ACTION_KEEP_LANE = 0,         /* "keep_lane"         -> target 15.0 m/s, lane change 0  */
+  SMX_ACTION_SLOW_DOWN = 1,         /* "slow_down"         -> target  0.0 m/s, lane change 0  */
+  SMX_ACTION_CHANGE_LANE_LEFT = 2,  /* "change_lane_left"  -> target 12.5 m/s, lane change +1 */
+  SMX_ACTION_CHANGE_LANE_RIGHT = 3, /* "change_lane_right" -> target 12.5 m/s, lane change -1 */
+  SMX_ACTION_NONE = -1              /* agent sent no action this tick (smarts.py:1233-1240) */
+};
+
+/* ---- done criteria bits: reference smarts/core/agent_interface.py:186-206 ---- */
+enum {
+  SMX_DONE_COLLISION = 1 << 0,
+  SMX_DONE_OFF_ROAD = 1 << 1,
+  SMX_DONE_OFF_ROUTE = 1 << 2,
+  SMX_DONE_ON_SHOULDER = 1 << 3,
+  SMX_DONE_WRONG_WAY = 1 << 4,
+  SMX_DONE_NOT_MOVING = 1 << 5
+};
+
+/* ---- event columns of smx_outputs.events, order of reference smarts/core/events.py:23-34 ---- */
+enum {
+  SMX_EV_COLLISIONS = 0,
+  SMX_EV_OFF_ROAD = 1,
+  SMX_EV_OFF_ROUTE = 2,
+  SMX_EV_ON_SHOULDER = 3,
+  SMX_EV_WRONG_WAY = 4,
+  SMX_EV_NOT_MOVING = 5,
+  SMX_EV_REACHED_GOAL = 6,
+  SMX_EV_REACHED_MAX_EPISODE_STEPS = 7,
+  SMX_EV_AGENTS_ALIVE_DONE = 8,
+  SMX_EV_COUNT = 9
+};
+
+/* ---- sensor switches: reference smarts/core/agent_interface.py:209-297 ---- */
+enum {
+  SMX_SENSOR_WAYPOINTS = 1 << 0,
+  SMX_SENSOR_NEIGHBORS = 1 << 1,
+  SMX_SENSOR_ACCELEROMETER = 1 << 2,
+  SMX_SENSOR_OGM = 1 << 3,
+  SMX_SENSOR_LIDAR = 1 << 4
+};
+
+typedef struct smx_config {
+  int32_t num_envs;          /* E: environment instances in this shard            */
+  int32_t num_vehicles;      /* N: vehicle slots per instance (<= 64)             */
+  double dt;                 /* fixed_timestep_sec, reference hiway_env.py:113    */
+  uint32_t sensors;          /* SMX_SENSOR_* bits                                 */
+  uint32_t done_criteria;    /* SMX_DONE_* bits                                   */
+  int32_t wp_lookahead;      /* Waypoints.lookahead (agent_interface.py:78), 32   */
+  int32_t wp_paths;          /* dense rows kept per agent, format_obs.py:42 -> 4  */
+  int32_t wp_len;            /* dense waypoints kept per path, format_obs.py:42 -> 20 */
+  int32_t nb_max;            /* dense neighbour rows, format_obs.py:41 -> 10      */
+  double nb_radius;          /* NeighborhoodVehicles.radius; < 0 = unlimited      */
+  int32_t max_episode_steps; /* <= 0 = None                                       */
+  double not_moving_time;    /* EventConfiguration, agent_interface.py:175-183    */
+  double not_moving_distance;
+  int32_t auto_reset;        /* ParallelEnv auto_reset, parallel_env.py:303-309   */
+  int32_t reset_elapsed_steps; /* ticks the reference spends before the first ego
+                                  observation exists (smarts.py:426-434)          */
+  int32_t ogm_width, ogm_height; /* OGM sensor grid (agent_interface.py:42-51)    */
+  double ogm_resolution;
+  int32_t lidar_rays;        /* number of rays in smx_lidar_rays                  */
+  double lidar_max_distance;
+} smx_config;
+
+/* Host-side SoA map tables produced by smarts_amd.map_compiler.compile_map().
+ * smx_load_map copies them to the device.  Lane order = sumolib _allLanes order. */
+typedef struct smx_map_tables {
+  int32_t n_lanes, n_roads, n_lanepoints, n_shape_pts, n_segments;
+  const int32_t* lane_road;
+  const int32_t* lane_index;
+  const double* lane_width;
+  const double* lane_speed;
+  const double* lane_length;     /* the net.xml length attribute (sumo_road_network.py:283-285) */
+  const uint8_t* lane_in_junction;
+  const int32_t* lane_shape_off; /* n_lanes + 1 */
+  const double* shape_x;
+  const double* shape_y;
+  const int32_t* lane_out_off;   /* n_lanes + 1 */
+  const int32_t* lane_out_idx;
+  const int32_t* road_lane_off;  /* n_roads + 1 */
+  const int32_t* road_lanes;
+  const uint8_t* road_is_junction;
+  const int32_t* road_out_road;
+  const double* lp_x;
+  const double* lp_y;
+  const double* lp_heading;
+  const double* lp_dirx;
+  const double* lp_diry;
+  const int32_t* lp_lane;
+  const uint8_t* lp_inferred;
+  const int32_t* lp_next_off;    /* n_lanepoints + 1 */
+  const int32_t* lp_next_idx;
+  double lpg_x0, lpg_y0, lpg_cell;
+  int32_t lpg_nx, lpg_ny;
+  const int32_t* lpg_off;        /* lpg_nx * lpg_ny + 1 */
+  const int32_t* lpg_idx;
+  const int32_t* seg_lane;
+  const int32_t* seg_v0;
+  double sg_x0, sg_y0, sg_cell;
+  int32_t sg_nx, sg_ny;
+  const int32_t* sg_off;         /* sg_nx * sg_ny + 1 */
+  const int32_t* sg_idx;
+  double default_lane_width;     /* sumo_road_network.py:80 */
+} smx_map_tables;
+
+/* ---- simulation state, caller-owned device memory, struct-of-arrays over (E, N) ---- */
+enum {
+  SMX_S_X = 0, SMX_S_Y, SMX_S_HEADING,   /* pose of the base frame (chassis.py:493-505) */
+  SMX_S_U, SMX_S_V, SMX_S_R,             /* body-frame velocity + yaw rate               */
+  SMX_S_DELTA,                            /* steer joint angle (chassis.py:510-525)       */
+  SMX_S_LAT_INT, SMX_S_SPD_INT, SMX_S_STEER, SMX_S_THROTTLE, SMX_S_SPD_ERR,
+  SMX_S_MCL_X, SMX_S_MCL_Y,              /* LaneFollowingControllerState (lane_following_controller.py:34-49) */
+  SMX_S_TRIP_X, SMX_S_TRIP_Y, SMX_S_TRIP_H, SMX_S_DIST, /* TripMeterSensor (sensors.py:880-947) */
+  SMX_S_LV0_LONG, SMX_S_LV0_LAT, SMX_S_AV0_Z,           /* AccelerometerSensor history (sensors.py:1046-1087) */
+  SMX_S_LV1_LONG, SMX_S_LV1_LAT, SMX_S_AV1_Z,
+  SMX_S_PATH_SUM,                        /* DrivenPathSensor running window length (sensors.py:855-877) */
+  SMX_S_COUNT
+};
+enum {
+  SMX_F_ALIVE = 1 << 0,
+  SMX_F_MCL_SET = 1 << 1,
+  SMX_F_TRIP_HAS_WP = 1 << 2,
+  SMX_F_HIST_SHIFT = 3 /* bits 3-4: accelerometer samples held (0..2) */
+};
+
+#define SMX_DRIVEN_PATH_LEN 500 /* DrivenPathSensor deque, sensors.py:838 */
+
+typedef struct smx_state {
+  double* f64;        /* [SMX_S_COUNT][E*N]                                    */
+  int32_t* flags;     /* [E*N]  SMX_F_* bits                                   */
+  int32_t* steps;     /* [E*N]  SensorState._step (sensors.py:609-637)         */
+  int32_t* env_ticks; /* [E]    ticks since reset (elapsed_sim_time = ticks*dt)*/
+  int32_t* env_done_count; /* [E] agents that have ever been done (hiway_env.py:258-261) */
+  int32_t* env_episode;    /* [E] episodes completed (indexes the spawn table) */
+  double* driven_path; /* [E*N][SMX_DRIVEN_PATH_LEN] ring of step lengths, or NULL
+                         when SMX_DONE_NOT_MOVING tracking is not wanted        */
+} smx_state;
+
+/* Spawn table: episode k of env e starts from row (k mod episodes).
+ * x, y = vehicle centre, heading in reference convention, speed m/s. */
+typedef struct smx_spawns {
+  int32_t episodes;
+  const double* pose; /* device, [episodes][E*N][4] = x, y, heading, speed */
+} smx_spawns;
+
+/* ---- per-tick outputs, caller-owned device memory, dense StdObs layout
+ *      (reference smarts/env/wrappers/format_obs.py:40-42, 313-373, 401-603) ---- */
+enum { /* columns of smx_outputs.ego_f32 */
+  SMX_EGO_HEADING = 0, SMX_EGO_SPEED, SMX_EGO_STEERING, SMX_EGO_YAW_RATE,
+  SMX_EGO_LIN_VEL = 4,  /* 3 */
+  SMX_EGO_ANG_VEL = 7,  /* 3 */
+  SMX_EGO_LIN_ACC = 10, /* 3 */
+  SMX_EGO_ANG_ACC = 13, /* 3 */
+  SMX_EGO_LIN_JERK = 16,/* 3 */
+  SMX_EGO_ANG_JERK = 19,/* 3 */
+  SMX_EGO_BOX = 22,     /* 3: length, width, height */
+  SMX_EGO_F32_COUNT = 25
+};
+
+typedef struct smx_outputs {
+  double* ego_pos;       /* [E*N][3]                                          */
+  float* ego_f32;        /* [E*N][SMX_EGO_F32_COUNT]                          */
+  int16_t* ego_lane;     /* [E*N][2] = lane id (table index, -1 none), lane_index */
+  uint8_t* events;       /* [E*N][SMX_EV_COUNT]                               */
+  double* reward;        /* [E*N] trip-meter increment (agent_manager.py:233) */
+  double* dist;          /* [E*N] distance_travelled / score                  */
+  uint8_t* done;         /* [E*N]                                             */
+  uint8_t* active;       /* [E*N] 1 while the agent has a vehicle after this tick */
+  uint8_t* env_done;     /* [E]   dones["__all__"] (hiway_env.py:258-261)     */
+  /* waypoints sensor, [E*N][wp_paths][wp_len] */
+  double* wp_pos;        /* ...[3], z = 0 (format_obs.py:594)                 */
+  float* wp_heading;
+  float* wp_lane_width;
+  float* wp_speed_limit;
+  int8_t* wp_lane_index;
+  int16_t* wp_lane_id;   /* extra: lane table index of each waypoint          */
+  uint8_t* wp_count;     /* [E*N][wp_paths + 1]: total #paths, then #waypoints per kept path */
+  /* neighbourhood sensor, [E*N][nb_max] */
+  double* nb_pos;        /* ...[3]                                            */
+  float* nb_box;         /* ...[3]                                            */
+  float* nb_heading;
+  float* nb_speed;
+  int8_t* nb_lane_index; /* -1 when no lane within the observer's length      */
+  int16_t* nb_lane_id;
+  int8_t* nb_slot;       /* vehicle slot of each neighbour, -1 = padding      */
+  uint8_t* nb_count;     /* [E*N] neighbours found (may exceed nb_max)        */
+  /* occupancy grid sensor [E*N][ogm_height][ogm_width], NULL if unused       */
+  uint8_t* ogm;
+  /* lidar sensor [E*N][lidar_rays]: hit flag + point, NULL if unused         */
+  uint8_t* lidar_hit;
+  double* lidar_point;   /* ...[3]                                            */
+} smx_outputs;
+
+/* ---- entry points ---- */
+int smx_create(const smx_config* cfg, int device, smx_handle* out);
+int smx_load_map(smx_handle h, const smx_map_tables* map);
+/* Base ray directions (device, [lidar_rays][3]); reference lidar.py:89-113 */
+int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t n_rays);
+/* Re-initialise the envs whose mask byte is non-zero (NULL = all) from the spawn
+ * table and produce their first observations. */
+int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, const smx_spawns* sp,
+              const smx_outputs* out, void* hip_stream);
+/* One tick for every env: actions[E*N] are SMX_ACTION_* (int8, device). */
+int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
+             const smx_outputs* out, void* hip_stream);
+int smx_sync(smx_handle h, void* hip_stream);
+/* Device-side timing of the last smx_step on `hip_stream` (hipEvents recorded
+ * around the launch); returns milliseconds in *ms. */
+int smx_last_step_ms(smx_handle h, float* ms);
+int smx_set_timing(smx_handle h, int enabled);
+const char* smx_last_error(smx_handle h);
+const char* smx_version(void);
+void smx_destroy(smx_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMX_H */

@@ -139,12 +139,28 @@ class OracleEnv:
         """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre)."""
         self.road_map = road_map
         self.dt = dt
-        self.elapsed_sim_time = 0.0
-        self.step_count = 0
         self._round = rm.round_param_for_dt(dt)
+        # SMARTS.reset spins step({}) until the traps have fired (smarts.py:426-434): the ego
+        # vehicles appear once mission.start_time = 0.1 s has *passed* (trap_manager.py:53-65)
+        self.reset_steps = int(math.floor(0.1 / dt + 1e-9)) + 1
+        self.elapsed_sim_time = 0.0
+        for _ in range(self.reset_steps):
+            self.elapsed_sim_time = round(self.elapsed_sim_time + dt, self._round)
+        self.step_count = self.reset_steps - 1
         self.agents = [
             _Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(np.asarray(spawns, dtype=np.float64), configs)
         ]
+
+    def reset_observe(self):
+        """The observations ``SMARTS.reset`` returns: sensors run on the just-created vehicles
+        (no controller, no physics yet)."""
+        alive_states = [(j, a.body) for j, a in enumerate(self.agents) if a.alive]
+        obs = {}
+        for i, ag in enumerate(self.agents):
+            ag.steps += 1
+            obs[i], _ = self._observe(i, ag, alive_states)
+        self.step_count += 1
+        return obs
 
     # ------------------------------------------------------------------ tick
     def step(self, actions):
@@ -153,7 +169,12 @@ class OracleEnv:
         self.elapsed_sim_time = round(self.elapsed_sim_time + self.dt, self._round)  # smarts.py:261-262
         # 2. controllers (smarts.py:1233-1263)
         for ag, action in zip(self.agents, actions):
-            if not ag.alive or action is None:
+            if not ag.alive:
+                continue
+            if action is None or (not isinstance(action, str) and int(action) < 0):
+                # no action this tick (controllers/__init__.py:87-88): wheel torques last one
+                # physics step only, the steer motor keeps its target
+                ag.body.control(throttle=0.0, brake=0.0, steering=ag.ctrl.steering_state)
                 continue
             if not isinstance(action, str):
                 action = ctl.LANE_ACTION_NAMES[int(action)]

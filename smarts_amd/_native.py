@@ -1,0 +1,152 @@
+"""ctypes binding of include/smx.h (libsmarts_mi355x.so).
+
+There is no CPU fallback: if the HIP extension is missing or does not load, every
+use of the product path raises.  (The CPU restatement under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import LIB_PATH
+
+# ---- enums (include/smx.h) ----
+ACTION_KEEP_LANE, ACTION_SLOW_DOWN, ACTION_CHANGE_LANE_LEFT, ACTION_CHANGE_LANE_RIGHT = 0, 1, 2, 3
+ACTION_NONE = -1
+DONE_COLLISION, DONE_OFF_ROAD, DONE_OFF_ROUTE = 1, 2, 4
+DONE_ON_SHOULDER, DONE_WRONG_WAY, DONE_NOT_MOVING = 8, 16, 32
+(EV_COLLISIONS, EV_OFF_ROAD, EV_OFF_ROUTE, EV_ON_SHOULDER, EV_WRONG_WAY, EV_NOT_MOVING, EV_REACHED_GOAL,
+ EV_REACHED_MAX_EPISODE_STEPS, EV_AGENTS_ALIVE_DONE, EV_COUNT) = range(10)
+EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way", "not_moving", "reached_goal",
+               "reached_max_episode_steps", "agents_alive_done"]
+SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
+STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
+                "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
+                "LV1_LAT", "AV1_Z", "PATH_SUM"]
+S = {name: i for i, name in enumerate(STATE_FIELDS)}
+S_COUNT = len(STATE_FIELDS)
+F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT = 1, 2, 4, 3
+DRIVEN_PATH_LEN = 500
+EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,
+           ANG_JERK=19, BOX=22)
+EGO_F32_COUNT = 25
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_f64 = C.c_double
+
+
+class SmxConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", _i32), ("num_vehicles", _i32), ("dt", _f64), ("sensors", C.c_uint32),
+        ("done_criteria", C.c_uint32), ("wp_lookahead", _i32), ("wp_paths", _i32), ("wp_len", _i32),
+        ("nb_max", _i32), ("nb_radius", _f64), ("max_episode_steps", _i32), ("not_moving_time", _f64),
+        ("not_moving_distance", _f64), ("auto_reset", _i32), ("reset_elapsed_steps", _i32),
+        ("ogm_width", _i32), ("ogm_height", _i32), ("ogm_resolution", _f64), ("lidar_rays", _i32),
+        ("lidar_max_distance", _f64),
+    ]
+
+
+class SmxMapTables(C.Structure):
+    _fields_ = [
+        ("n_lanes", _i32), ("n_roads", _i32), ("n_lanepoints", _i32), ("n_shape_pts", _i32), ("n_segments", _i32),
+        ("lane_road", _p), ("lane_index", _p), ("lane_width", _p), ("lane_speed", _p), ("lane_length", _p),
+        ("lane_in_junction", _p), ("lane_shape_off", _p), ("shape_x", _p), ("shape_y", _p),
+        ("lane_out_off", _p), ("lane_out_idx", _p), ("road_lane_off", _p), ("road_lanes", _p),
+        ("road_is_junction", _p), ("road_out_road", _p),
+        ("lp_x", _p), ("lp_y", _p), ("lp_heading", _p), ("lp_dirx", _p), ("lp_diry", _p), ("lp_lane", _p),
+        ("lp_inferred", _p), ("lp_next_off", _p), ("lp_next_idx", _p),
+        ("lpg_x0", _f64), ("lpg_y0", _f64), ("lpg_cell", _f64), ("lpg_nx", _i32), ("lpg_ny", _i32),
+        ("lpg_off", _p), ("lpg_idx", _p), ("seg_lane", _p), ("seg_v0", _p),
+        ("sg_x0", _f64), ("sg_y0", _f64), ("sg_cell", _f64), ("sg_nx", _i32), ("sg_ny", _i32),
+        ("sg_off", _p), ("sg_idx", _p), ("default_lane_width", _f64),
+    ]
+
+
+class SmxState(C.Structure):
+    _fields_ = [("f64", _p), ("flags", _p), ("steps", _p), ("env_ticks", _p), ("env_done_count", _p),
+                ("env_episode", _p), ("driven_path", _p)]
+
+
+class SmxSpawns(C.Structure):
+    _fields_ = [("episodes", _i32), ("pose", _p)]
+
+
+OUTPUT_FIELDS = [
+    "ego_pos", "ego_f32", "ego_lane", "events", "reward", "dist", "done", "active", "env_done",
+    "wp_pos", "wp_heading", "wp_lane_width", "wp_speed_limit", "wp_lane_index", "wp_lane_id", "wp_count",
+    "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
+    "ogm", "lidar_hit", "lidar_point",
+]
+
+
+class SmxOutputs(C.Structure):
+    _fields_ = [(name, _p) for name in OUTPUT_FIELDS]
+
+
+EXPORTS = [
+    "smx_create", "smx_load_map", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
+    "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load the HIP extension; raises NativeLibraryError (never falls back)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("SMX_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} not found: build it with `python -m smarts_amd.build` (hipcc --offload-arch=gfx950); "
+            "smarts_amd has no CPU fallback"
+        )
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f"cannot load {path}: {e}") from e
+    h = C.c_void_p
+    lib.smx_create.argtypes = [C.POINTER(SmxConfig), C.c_int, C.POINTER(h)]
+    lib.smx_create.restype = C.c_int
+    lib.smx_load_map.argtypes = [h, C.POINTER(SmxMapTables)]
+    lib.smx_load_map.restype = C.c_int
+    lib.smx_set_lidar_rays.argtypes = [h, _p, _i32]
+    lib.smx_set_lidar_rays.restype = C.c_int
+    lib.smx_reset.argtypes = [h, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
+    lib.smx_reset.restype = C.c_int
+    lib.smx_step.argtypes = [h, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
+    lib.smx_step.restype = C.c_int
+    lib.smx_sync.argtypes = [h, _p]
+    lib.smx_sync.restype = C.c_int
+    lib.smx_last_step_ms.argtypes = [h, C.POINTER(C.c_float)]
+    lib.smx_last_step_ms.restype = C.c_int
+    lib.smx_set_timing.argtypes = [h, C.c_int]
+    lib.smx_set_timing.restype = C.c_int
+    lib.smx_set_controller_gains.argtypes = [h, _f64, _f64]
+    lib.smx_set_controller_gains.restype = C.c_int
+    lib.smx_last_error.argtypes = [h]
+    lib.smx_last_error.restype = C.c_char_p
+    lib.smx_version.argtypes = []
+    lib.smx_version.restype = C.c_char_p
+    lib.smx_destroy.argtypes = [h]
+    lib.smx_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+def check(lib, handle, rc: int, what: str):
+    if rc != 0:
+        msg = lib.smx_last_error(handle)
+        raise SmxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,143 @@
+// smx_device.h — device-side tables and numeric helpers shared by the kernels.
+// gfx950 only.  Built with -ffp-contract=off: the integer / flag outputs of this path
+// (lane ids, events, done) hang on floating-point comparisons, so products and sums
+// must round exactly like the reference's Python floats (no FMA contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/smx.h"
+
+#define SMX_PI 3.141592653589793
+#define SMX_TWO_PI 6.283185307179586
+#define SMX_HALF_PI 1.5707963267948966
+
+// Device copy of smx_map_tables (same field meaning, device pointers).
+struct MapDev {
+  int32_t n_lanes, n_roads, n_lanepoints, n_shape_pts, n_segments;
+  const int32_t* lane_road;
+  const int32_t* lane_index;
+  const double* lane_width;
+  const double* lane_speed;
+  const double* lane_length;
+  const uint8_t* lane_in_junction;
+  const int32_t* lane_shape_off;
+  const double* shape_x;
+  const double* shape_y;
+  const int32_t* lane_out_off;
+  const int32_t* lane_out_idx;
+  const int32_t* road_lane_off;
+  const int32_t* road_lanes;
+  const uint8_t* road_is_junction;
+  const int32_t* road_out_road;
+  const double* lp_x;
+  const double* lp_y;
+  const double* lp_heading;
+  const double* lp_dirx;
+  const double* lp_diry;
+  const int32_t* lp_lane;
+  const uint8_t* lp_inferred;
+  const int32_t* lp_next_off;
+  const int32_t* lp_next_idx;
+  double lpg_x0, lpg_y0, lpg_cell;
+  int32_t lpg_nx, lpg_ny;
+  const int32_t* lpg_off;
+  const int32_t* lpg_idx;
+  const int32_t* seg_lane;
+  const int32_t* seg_v0;
+  double sg_x0, sg_y0, sg_cell;
+  int32_t sg_nx, sg_ny;
+  const int32_t* sg_off;
+  const int32_t* sg_idx;
+  double default_lane_width;
+};
+
+// ---------------------------------------------------------------------------------
+// angle helpers (reference smarts/core/utils/math.py, smarts/core/coordinates.py)
+// ---------------------------------------------------------------------------------
+// Python / numpy float modulo for a positive divisor.
+__device__ __forceinline__ double py_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0 && m < 0.0) m += b;
+  return m;
+}
+
+// Heading.__new__ (coordinates.py:175-184): wrap to (-pi, pi].
+__device__ __forceinline__ double wrap_heading(double x) {
+  double v = py_mod(x, SMX_TWO_PI);
+  if (v > SMX_PI) v -= SMX_TWO_PI;
+  return v;
+}
+
+// Heading.relative_to (coordinates.py:227-239).
+__device__ __forceinline__ double heading_relative_to(double h, double other) {
+  return wrap_heading(wrap_heading(h - other));
+}
+
+// min_angles_difference_signed (math.py:447-449).
+__device__ __forceinline__ double min_angles_difference_signed(double first, double second) {
+  return py_mod((first - second) + SMX_PI, SMX_TWO_PI) - SMX_PI;
+}
+
+// vec_to_radians (math.py:256-277).
+__device__ __forceinline__ double vec_to_radians(double x, double y) {
+  double r = atan2(fabs(y), fabs(x));
+  if (x < 0.0) {
+    if (y < 0.0) return py_mod(r + 0.5 * SMX_PI, SMX_TWO_PI);
+    return py_mod(0.5 * SMX_PI - r, SMX_TWO_PI);
+  } else if (y < 0.0) {
+    return py_mod(1.5 * SMX_PI - r, SMX_TWO_PI);
+  }
+  return py_mod(r - 0.5 * SMX_PI, SMX_TWO_PI);
+}
+
+// radians_to_vec (math.py:247-253).
+__device__ __forceinline__ void radians_to_vec(double radians, double& vx, double& vy) {
+  double angle = py_mod(radians + SMX_PI * 0.5, SMX_TWO_PI);
+  vx = cos(angle);
+  vy = sin(angle);
+}
+
+// lerp (math.py:206-216).
+__device__ __forceinline__ double lerp_ref(double a, double b, double p) { return a * (1.0 - p) + b * p; }
+
+__device__ __forceinline__ double clip_ref(double v, double lo, double hi) {
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// signed_dist_to_line (math.py:163-185): point p, line through lp with direction d.
+__device__ __forceinline__ double signed_dist_to_line(double px, double py, double lx, double ly, double dx,
+                                                      double dy) {
+  double p2x = lx + dx, p2y = ly + dy;
+  double u = fabs(dy * px - dx * py + p2x * ly - p2y * lx);
+  double d = u / sqrt(dx * dx + dy * dy);
+  double nx = -dy, ny = dx;
+  double dot = (px - lx) * nx + (py - ly) * ny;
+  double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
+  return d * sgn;
+}
+
+// ---------------------------------------------------------------------------------
+// point <-> lane centre line (sumolib.geomhelper twins: math.py:293-433)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double euclid(double ax, double ay, double bx, double by) {
+  double dx = ax - bx, dy = ay - by;
+  return sqrt(dx * dx + dy * dy);
+}
+
+// distance_point_to_line(point, p1, p2, perpendicular=False) (math.py:393-411)
+__device__ __forceinline__ double dist_point_segment(double px, double py, double x1, double y1, double x2,
+                                                     double y2) {
+  double d = euclid(x1, y1, x2, y2);
+  double u = ((px - x1) * (x2 - x1)) + ((py - y1) * (y2 - y1));
+  double offset;
+  if (d == 0.0 || u < 0.0 || u > d * d) {
+    offset = (u < 0.0) ? 0.0 : d;
+  } else {
+    offset = u / d;
+  }
+  if (offset == 0.0) return euclid(px, py, x1, y1);
+  double uu = offset / d;
+  double ix = x1 + uu * (x2 - x1), iy = y1 + uu * (y2 - y1);
+  return euclid(px, py, ix, iy);
+}

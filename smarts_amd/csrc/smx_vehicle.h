@@ -1,0 +1,372 @@
+// smx_vehicle.h — per-vehicle control + dynamics on the device.
+//   Controllers.perform_action (Lane space)          controllers/__init__.py:125-144
+//   LaneFollowingController.perform_lane_following   lane_following_controller.py:63-365
+//   TrajectoryTrackingController.curvature_calculation trajectory_tracking_controller.py:444-473
+//   AckermannChassis.control / _apply_*              chassis.py:678-794
+//   SMARTS._step_pybullet substep schedule           smarts.py:602-613, 923-931
+// The rigid-body solve itself (pybullet, not in the reference tree) is the planar single-track
+// model documented in DESIGN.md "Substitutions"; constants come from models/vehicle.urdf,
+// models/controller_parameters.yaml and models/plane.urdf.
+#pragma once
+#include "smx_roadmap.h"
+
+// ---- models/controller_parameters.yaml:17-25 ("sedan") ----
+#define SMX_WHEEL_RADIUS 0.31265
+#define SMX_MAX_TORQUE 1600.0
+#define SMX_MAX_BTORQUE 1400.0
+#define SMX_MAX_STEERING 12.56
+#define SMX_STEERING_GEAR_RATIO 17.4
+// ---- models/vehicle.urdf ----
+#define SMX_TOTAL_MASS (2356.0 + 4 * 15.0 + 2 * 1.0 + 1.0)
+#define SMX_AXLE_DIST 1.5
+#define SMX_TRACK_HALF 0.5
+#define SMX_TOTAL_INERTIA_Z (2681.95008628 + (4 * 15.0 + 2 * 1.0) * (1.5 * 1.5 + 0.5 * 0.5))
+#define SMX_WHEELBASE 3.0
+#define SMX_STEER_LIMIT 0.8727
+#define SMX_CHASSIS_LENGTH 3.68
+#define SMX_CHASSIS_WIDTH 1.47
+#define SMX_CHASSIS_HEIGHT 1.0
+#define SMX_BASE_HEIGHT (0.31265 - 0.3)
+// ---- models/plane.urdf, smarts.py:67,615 ----
+#define SMX_CORNERING_STIFFNESS 100000.0
+#define SMX_GROUND_FRICTION 3.0
+#define SMX_GRAVITY 9.8
+#define SMX_MAX_PYBULLET_FREQ 240
+#define SMX_STEER_POSITION_GAIN 0.1
+#define SMX_KINEMATIC_BELOW_SPEED 2.0
+
+struct VehState {
+  double x, y, heading, u, v, r, delta;
+};
+
+struct CtrlState {
+  double lat_int, spd_int, steer, throttle, spd_err, mcl_x, mcl_y;
+  bool mcl_set;
+};
+
+// chassis.py:558-566 (body-frame speeds recovered from the world velocity, as the reference does)
+__device__ __forceinline__ void world_velocity(const VehState& s, double& vx, double& vy) {
+  double sh = sin(s.heading), ch = cos(s.heading);
+  // forward = (-sin h, cos h); left = (-cos h, -sin h)
+  vx = s.u * (-sh) + s.v * (-ch);
+  vy = s.u * ch + s.v * (-sh);
+}
+
+__device__ __forceinline__ void long_lat_speed(const VehState& s, double& lng, double& lat) {
+  double vx, vy;
+  world_velocity(s, vx, vy);
+  double sh = sin(s.heading), ch = cos(s.heading);
+  lng = vy * ch - vx * sh;
+  lat = vy * sh + vx * ch;
+}
+
+__device__ __forceinline__ double vehicle_speed(const VehState& s) {
+  double vx, vy;
+  world_velocity(s, vx, vy);
+  return sqrt(vx * vx + vy * vy + 0.0 * 0.0);
+}
+
+// curvature_calculation on the first waypoints of the chosen path, kept in registers.
+struct Traj10 {
+  double x[10], y[10], h[10];
+  int n;
+};
+
+__device__ __forceinline__ double curvature_calculation(const Traj10& t, int offset) {
+  const int num_points = 5;
+  if (t.n <= num_points + offset) return 1e20;
+  double hs = 0.0, ds = 0.0;
+#pragma unroll
+  for (int i = 0; i < num_points; ++i) {
+    // static indexing after unroll: offset is 0 or 4
+    double h1, h0, x0, x1, y0, y1;
+    if (offset == 0) {
+      h1 = t.h[i + 1];
+      h0 = t.h[i];
+      x0 = t.x[i];
+      x1 = t.x[i + 1];
+      y0 = t.y[i];
+      y1 = t.y[i + 1];
+    } else {
+      h1 = t.h[i + 5];
+      h0 = t.h[i + 4];
+      x0 = t.x[i + 4];
+      x1 = t.x[i + 5];
+      y0 = t.y[i + 4];
+      y1 = t.y[i + 5];
+    }
+    hs += min_angles_difference_signed(h1, h0);
+    double ex = x0 - x1, ey = y0 - y1;
+    ds += fabs(sqrt(ex * ex + ey * ey));
+  }
+  if (hs == 0.0) return 1e20;
+  return ds / hs;
+}
+
+struct ControlOut {
+  double throttle, brake, steering;
+};
+
+// lane_following_controller.py:63-365.  Lateral gains: place_poles (:376-437) lands outside the
+// clip window for every target speed of the Lane action space, so they are the clip bounds
+// (0.04, 3.4) for target_speed > 0 and the literals (0.01, 0.36) at 0 — verified against scipy in
+// tests/test_host_logic.py.
+__device__ inline ControlOut lane_following_control(const MapDev& m, const VehState& s, CtrlState& cs, double dt,
+                                                    double target_speed, int lane_change,
+                                                    double heading_error_gain, double lateral_error_gain) {
+  const double px = s.x, py = s.y;
+  const double speed = vehicle_speed(s);
+  // ---- waypoint paths, lookahead 16, route = the agent's (empty) route (:96-98)
+  PathSeed seed = resolve_path_seed(m, px, py, s.heading, 5.0, true);
+  ControlOut out;
+  out.throttle = cs.throttle;
+  out.brake = 0.0;
+  out.steering = cs.steer;
+  if (seed.road < 0) return out;  // reference asserts "no waypoints found"; keep the last command
+
+  // pass A: the path nearest to the vehicle by its first waypoint (find_current_lane :367-374);
+  // paths are numbered in the reference's order: lanes by index, branches depth-first.
+  const int la = m.road_lane_off[seed.road], lb = m.road_lane_off[seed.road + 1];
+  int n_paths = 0;
+  int best_path = 0;
+  double best_d = SMX_INF;
+  for (int li = la; li < lb; ++li) {
+    int lane = m.road_lanes[li];
+    int start = closest_lanepoint_filtered(m, px, py, lane, false);
+    if (start < 0) continue;
+    BranchState bs;
+    bs.reset();
+    do {
+      double fx = 0.0, fy = 0.0;
+      equally_spaced_path(m, seed.f, bs, start, 16, px, py, 1, [&](int, const WaypointOut& w) {
+        fx = w.x;
+        fy = w.y;
+      });
+      double ex = fx - px, ey = fy - py;
+      double d = sqrt(ex * ex + ey * ey);
+      if (d < best_d) {
+        best_d = d;
+        best_path = n_paths;
+      }
+      ++n_paths;
+    } while (bs.advance());
+  }
+  if (n_paths == 0) return out;
+  int want = best_path + lane_change;
+  want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
+
+  // pass B: synthesise the chosen path and fold it into the controller's quantities
+  Traj10 tr;
+  tr.n = 0;
+  double ewma_acc[17];  // headings of the chosen path (static indexing only)
+  int wp_n = 0;
+  double wp3x = 0, wp3y = 0, wp3h = 0, wp4x = 0, wp4y = 0, wp4h = 0, wp0h = 0;
+  double lastx = 0, lasty = 0, lasth = 0;
+  {
+    int idx = 0;
+    bool found = false;
+    for (int li = la; li < lb && !found; ++li) {
+      int lane = m.road_lanes[li];
+      int start = closest_lanepoint_filtered(m, px, py, lane, false);
+      if (start < 0) continue;
+      BranchState bs;
+      bs.reset();
+      do {
+        if (idx == want) {
+          wp_n = equally_spaced_path(m, seed.f, bs, start, 16, px, py, 17, [&](int i, const WaypointOut& w) {
+#pragma unroll
+            for (int k = 0; k < 17; ++k)
+              if (k == i) ewma_acc[k] = w.heading;
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+              if (k == i) {
+                tr.x[k] = w.x;
+                tr.y[k] = w.y;
+                tr.h[k] = w.heading;
+              }
+            if (i == 0) wp0h = w.heading;
+            if (i == 3) {
+              wp3x = w.x;
+              wp3y = w.y;
+              wp3h = w.heading;
+            }
+            if (i == 4) {
+              wp4x = w.x;
+              wp4y = w.y;
+              wp4h = w.heading;
+            }
+            lastx = w.x;
+            lasty = w.y;
+            lasth = w.heading;
+          });
+          found = true;
+          break;
+        }
+        // not the wanted path: walk it only to discover its branchings
+        equally_spaced_path(m, seed.f, bs, start, 16, px, py, 0, [&](int, const WaypointOut&) {});
+        ++idx;
+      } while (bs.advance());
+    }
+  }
+  if (wp_n <= 0) return out;
+  tr.n = wp_n < 10 ? wp_n : 10;
+
+  // road curviness (:105-118): EWMA over reversed consecutive pairs
+  double ewma = 0.0;
+#pragma unroll
+  for (int k = 15; k >= 0; --k) {
+    if (k + 1 < wp_n) {
+      double rel = heading_relative_to(ewma_acc[k], ewma_acc[k + 1]);
+      ewma = lerp_ref(ewma, fabs(rel) * (180.0 / SMX_PI), 0.03);
+    }
+  }
+  double road_curviness = clip_ref(ewma / 2.5, 0.0, 1.0);
+
+  double look_ahead_curvature = fabs(curvature_calculation(tr, 4));
+  if (look_ahead_curvature <= 2.0) {
+    // wp_path[4] exists whenever the curvature is finite (needs 10 points)
+    cs.mcl_x = wp4x;
+    cs.mcl_y = wp4y;
+    cs.mcl_set = true;
+  }
+  int look_ahead_wp_num = road_curviness > 0.5 ? 3 : 4;
+  look_ahead_wp_num = look_ahead_wp_num < wp_n - 1 ? look_ahead_wp_num : wp_n - 1;
+  double lax, lay, lah;
+  if (look_ahead_wp_num == 4) {
+    lax = wp4x;
+    lay = wp4y;
+    lah = wp4h;
+  } else if (look_ahead_wp_num == 3) {
+    lax = wp3x;
+    lay = wp3y;
+    lah = wp3h;
+  } else {
+    // short path: the look-ahead waypoint is the last one
+    lax = lastx;
+    lay = lasty;
+    lah = lasth;
+  }
+  double reference_heading = wp0h;
+  double ldx = lax - px, ldy = lay - py;
+  double look_ahead_dist = sqrt(ldx * ldx + ldy * ldy);
+  double vlx = px - look_ahead_dist * sin(s.heading);
+  double vly = py + look_ahead_dist * cos(s.heading);
+
+  double raw_throttle;
+  if (road_curviness < 0.3) {
+    raw_throttle = -3.6 * 1.8 * (speed - target_speed);
+  } else if (road_curviness > 0.3 && road_curviness < 0.8) {
+    raw_throttle = -0.6 * 3.6 * (speed - clip_ref(target_speed, 0.0, 6.94));
+  } else {
+    raw_throttle = -0.6 * 3.6 * (speed - clip_ref(target_speed, 0.0, 5.56));
+  }
+  double speed_error = speed - target_speed;
+  cs.spd_int += speed_error * dt;
+  double velocity_error_damping_term = (speed_error - cs.spd_err) / dt;
+  double lateral_force_coefficient = 1.5;
+  if (speed < 8.0 || target_speed < 6.0) lateral_force_coefficient = 0.0;
+  raw_throttle += (-0.2 * velocity_error_damping_term - 0.1 * cs.spd_int +
+                   fabs(lateral_force_coefficient * sin(cs.steer * (SMX_MAX_STEERING / SMX_STEERING_GEAR_RATIO))));
+  cs.spd_err = speed_error;
+
+  if (cs.mcl_set) {
+    double mx = px - cs.mcl_x, my = py - cs.mcl_y;
+    if (sqrt(mx * mx + my * my) < 2.0) reference_heading = lah;
+  }
+
+  double dvx, dvy;
+  radians_to_vec(lah, dvx, dvy);
+  double controller_lat_error = signed_dist_to_line(vlx, vly, lax, lay, dvx, dvy);
+
+  double curvature_radius = curvature_calculation(tr, 0);
+  double brake_norm = 0.0, throttle_norm;
+  double lng, lat;
+  long_lat_speed(s, lng, lat);
+  if (raw_throttle < 0.0) {
+    brake_norm = clip_ref(-raw_throttle, 0.0, 1.0);
+    throttle_norm = 0.0;
+  } else {
+    double traction_gain;
+    if (speed > 70.0 / 3.6 && fabs(curvature_radius) <= 1e3)
+      traction_gain = 4.5;
+    else if (40.0 / 3.6 <= speed && speed <= 70.0 / 3.6 && fabs(curvature_radius) <= 3.0)
+      traction_gain = 2.5;
+    else
+      traction_gain = 0.5;
+    throttle_norm = clip_ref(raw_throttle - traction_gain * 3.6 * fabs(lat), 0.0, 1.0);
+  }
+  cs.lat_int += dt * controller_lat_error;
+  double steering_feed_forward_gain = 0.15;
+  if (fabs(curvature_radius) < 7.0) steering_feed_forward_gain = 0.45;
+  double steering_controller_feed_forward = 1.0 * steering_feed_forward_gain * (1.0 / curvature_radius) * (speed * speed);
+  double normalized_speed = clip_ref(speed * 3.6 / 100.0, 0.0, 1.0);
+  double heading_speed_gain = -lerp_ref(0.5, 14.0, normalized_speed);
+  double yaw_rate_speed_gain = lerp_ref(5.75, 11.75, normalized_speed);
+  double lateral_speed_gain = clip_ref(lerp_ref(-1.0, 14.0, normalized_speed), 1.0, 2.0);
+  double max_steering_normalized = 1.0;
+  if (fabs(curvature_radius) > 1e7 && lane_change != 0) {
+    heading_speed_gain = -4.95;
+    yaw_rate_speed_gain = 1.0;
+    lateral_speed_gain = 0.22;
+    max_steering_normalized = 0.12;
+  }
+  double z_yaw = s.r;
+  double heading_error = min_angles_difference_signed(py_mod(s.heading, SMX_TWO_PI), reference_heading);
+  double steering_norm =
+      clip_ref(-heading_speed_gain * (heading_error_gain * (180.0 / SMX_PI)) * heading_error +
+                   lateral_speed_gain * lateral_error_gain * controller_lat_error + yaw_rate_speed_gain * z_yaw +
+                   0.3 * cs.lat_int - steering_controller_feed_forward,
+               -max_steering_normalized, max_steering_normalized);
+  // low_pass_filter (math.py:219-244)
+  cs.steer += dt * 5.5 * (steering_norm - cs.steer);
+  cs.steer = clip_ref(cs.steer + 0.0, -1.0, 1.0);
+  cs.throttle += dt * 2.0 * (throttle_norm - cs.throttle);
+  cs.throttle = clip_ref(cs.throttle + 0.0, 0.0, 1.0);
+  out.throttle = cs.throttle;
+  out.brake = brake_norm;
+  out.steering = cs.steer;
+  return out;
+}
+
+// AckermannChassis.control (chassis.py:678-718) + one SMARTS tick of the body model.
+__device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
+  double lng, lat;
+  long_lat_speed(s, lng, lat);
+  double brake = c.brake;
+  if (brake > 0.0 && lng < 1.0 / 36.0) brake = 0.0;
+  int substeps = (int)(dt * SMX_MAX_PYBULLET_FREQ);
+  if (substeps < 1) substeps = 1;
+  const double h = dt / (double)substeps;
+  const double delta_target = -c.steering * SMX_MAX_STEERING * (1.0 / SMX_STEERING_GEAR_RATIO);
+  const double drive_accel = 4.0 * (c.throttle * SMX_MAX_TORQUE) / SMX_WHEEL_RADIUS / SMX_TOTAL_MASS;
+  const double brake_decel = 4.0 * (brake * SMX_MAX_BTORQUE) / SMX_WHEEL_RADIUS / SMX_TOTAL_MASS;
+  const double f_max = 0.5 * SMX_GROUND_FRICTION * SMX_TOTAL_MASS * SMX_GRAVITY;
+  for (int k = 0; k < substeps; ++k) {
+    s.delta += SMX_STEER_POSITION_GAIN * (delta_target - s.delta);
+    s.delta = fmin(fmax(s.delta, -SMX_STEER_LIMIT), SMX_STEER_LIMIT);
+    double u = s.u, v = s.v, r = s.r;
+    double u_new = u + h * (drive_accel + v * r);
+    if (brake_decel > 0.0 && u_new > 0.0) u_new = fmax(0.0, u_new - h * brake_decel);
+    double v_new, r_new;
+    if (u_new >= SMX_KINEMATIC_BELOW_SPEED) {
+      double alpha_f = s.delta - (v + SMX_AXLE_DIST * r) / u_new;
+      double alpha_r = -(v - SMX_AXLE_DIST * r) / u_new;
+      double f_f = fmin(fmax(SMX_CORNERING_STIFFNESS * alpha_f, -f_max), f_max);
+      double f_r = fmin(fmax(SMX_CORNERING_STIFFNESS * alpha_r, -f_max), f_max);
+      v_new = v + h * ((f_f + f_r) / SMX_TOTAL_MASS - u_new * r);
+      r_new = r + h * (SMX_AXLE_DIST * (f_f - f_r) / SMX_TOTAL_INERTIA_Z);
+    } else {
+      r_new = u_new * tan(s.delta) / SMX_WHEELBASE;
+      v_new = r_new * SMX_AXLE_DIST;
+    }
+    double hd = s.heading;
+    double sh = sin(hd), ch = cos(hd);
+    s.x += h * (-u_new * sh - v_new * ch);
+    s.y += h * (u_new * ch - v_new * sh);
+    s.heading = hd + h * r_new;
+    s.u = u_new;
+    s.v = v_new;
+    s.r = r_new;
+  }
+  s.heading = wrap_heading(s.heading);
+}

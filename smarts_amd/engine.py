@@ -1,0 +1,313 @@
+"""Batched simulation engine: E environment instances x N vehicle slots on one GPU.
+
+Host-side owner of the device buffers (PyTorch-ROCm tensors, used purely as the
+zero-copy buffer type) and thin caller of the C-ABI (include/smx.h).  It plays the
+role of ``SMARTS`` (reference ``smarts/core/smarts.py``) for a whole shard:
+``reset`` ~ ``SMARTS.reset`` (:365-460), ``step`` ~ ``SMARTS.step`` (:187-227).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .map_compiler import CompiledMap
+
+
+@dataclass
+class SimConfig:
+    """Mirror of ``smx_config``; defaults follow the reference's AgentInterface / HiWayEnv."""
+
+    num_envs: int = 1
+    num_vehicles: int = 1
+    dt: float = 0.1  # hiway_env.py:113
+    waypoints: bool = True
+    neighbors: bool = False
+    accelerometer: bool = True  # agent_interface.py:291
+    wp_lookahead: int = 32  # agent_interface.py:78
+    wp_paths: int = 4  # format_obs.py:42
+    wp_len: int = 20
+    nb_max: int = 10  # format_obs.py:41
+    nb_radius: Optional[float] = None  # agent_interface.py:98
+    max_episode_steps: Optional[int] = None
+    done_collision: bool = True  # agent_interface.py:186-206
+    done_off_road: bool = True
+    done_off_route: bool = True
+    done_on_shoulder: bool = False
+    done_wrong_way: bool = False
+    done_not_moving: bool = False
+    not_moving_time: float = 60.0
+    not_moving_distance: float = 1.0
+    auto_reset: bool = False  # parallel_env.py:62
+    track_driven_path: bool = True
+
+    def sensors_mask(self) -> int:
+        m = 0
+        if self.waypoints:
+            m |= nat.SENSOR_WAYPOINTS
+        if self.neighbors:
+            m |= nat.SENSOR_NEIGHBORS
+        if self.accelerometer:
+            m |= nat.SENSOR_ACCELEROMETER
+        return m
+
+    def done_mask(self) -> int:
+        m = 0
+        for bit, on in (
+            (nat.DONE_COLLISION, self.done_collision), (nat.DONE_OFF_ROAD, self.done_off_road),
+            (nat.DONE_OFF_ROUTE, self.done_off_route), (nat.DONE_ON_SHOULDER, self.done_on_shoulder),
+            (nat.DONE_WRONG_WAY, self.done_wrong_way), (nat.DONE_NOT_MOVING, self.done_not_moving),
+        ):
+            if on:
+                m |= bit
+        return m
+
+    def reset_elapsed_steps(self) -> int:
+        """Ticks the reference burns in ``reset()`` before the first ego observation exists:
+        the trap fires once ``mission.start_time`` (0.1 s, plan.py:209) has *passed*
+        (trap_manager.py:53-65), and ``reset`` spins ``step({})`` until then (smarts.py:426-434)."""
+        return int(math.floor(0.1 / self.dt + 1e-9)) + 1
+
+
+def lane_heading(shape: np.ndarray, seg: int) -> float:
+    vx, vy = shape[seg + 1] - shape[seg]
+    # heading convention of the reference (0 = +y, counter-clockwise)
+    h = math.atan2(vy, vx) - math.pi / 2
+    return (h + math.pi) % (2 * math.pi) - math.pi
+
+
+def make_spawns(cm: CompiledMap, num_envs: int, num_vehicles: int, episodes: int = 1, seed: int = 42,
+                first_env: int = 0, min_gap: float = 8.0) -> np.ndarray:
+    """Synthetic spawn table: vehicle k of env e starts on lane (k mod L) of the
+    map's normal lanes at an arclength drawn U(0.05, 0.95)*lane_length from
+    ``numpy.random.Generator(PCG64(seed + e))``, re-drawn while within ``min_gap`` metres of an
+    earlier vehicle on that lane; heading = lane heading, speed = lane speed limit.
+    Returns ``[episodes, num_envs * num_vehicles, 4]`` (x, y, heading, speed)."""
+    lanes = [i for i in range(cm.n_lanes) if not cm.lane_in_junction[i]]
+    shapes = [cm.lane_shape(i) for i in lanes]
+    cums = []
+    for sh in shapes:
+        seg = np.sqrt(((sh[1:] - sh[:-1]) ** 2).sum(axis=1))
+        cums.append(np.concatenate(([0.0], np.cumsum(seg))))
+    out = np.zeros((episodes, num_envs * num_vehicles, 4), dtype=np.float64)
+    L = len(lanes)
+    for e in range(num_envs):
+        rng = np.random.Generator(np.random.PCG64(seed + first_env + e))
+        for ep in range(episodes):
+            taken: Dict[int, list] = {}
+            for k in range(num_vehicles):
+                li = k % L
+                cum = cums[li]
+                total = cum[-1]
+                for _ in range(1000):
+                    off = rng.uniform(0.05, 0.95) * total
+                    if all(abs(off - o) >= min_gap for o in taken.get(li, ())):
+                        break
+                taken.setdefault(li, []).append(off)
+                seg = int(np.searchsorted(cum, off, side="right") - 1)
+                seg = min(max(seg, 0), len(cum) - 2)
+                f = (off - cum[seg]) / (cum[seg + 1] - cum[seg]) if cum[seg + 1] > cum[seg] else 0.0
+                sh = shapes[li]
+                x = sh[seg, 0] + (sh[seg + 1, 0] - sh[seg, 0]) * f
+                y = sh[seg, 1] + (sh[seg + 1, 1] - sh[seg, 1]) * f
+                out[ep, e * num_vehicles + k] = (x, y, lane_heading(sh, seg), cm.lane_speed[lanes[li]])
+    return out
+
+
+_MAP_ARRAYS = [
+    ("lane_road", np.int32), ("lane_index", np.int32), ("lane_width", np.float64), ("lane_speed", np.float64),
+    ("lane_length", np.float64), ("lane_in_junction", np.uint8), ("lane_shape_off", np.int32),
+    ("shape_x", np.float64), ("shape_y", np.float64), ("lane_out_off", np.int32), ("lane_out_idx", np.int32),
+    ("road_lane_off", np.int32), ("road_lanes", np.int32), ("road_is_junction", np.uint8),
+    ("road_out_road", np.int32), ("lp_x", np.float64), ("lp_y", np.float64), ("lp_heading", np.float64),
+    ("lp_dirx", np.float64), ("lp_diry", np.float64), ("lp_lane", np.int32), ("lp_inferred", np.uint8),
+    ("lp_next_off", np.int32), ("lp_next_idx", np.int32), ("lpg_off", np.int32), ("lpg_idx", np.int32),
+    ("seg_lane", np.int32), ("seg_v0", np.int32), ("sg_off", np.int32), ("sg_idx", np.int32),
+]
+
+
+def map_tables_struct(cm: CompiledMap):
+    """Fill ``smx_map_tables`` with pointers into (kept-alive) contiguous numpy arrays."""
+    keep = []
+    t = nat.SmxMapTables()
+    t.n_lanes, t.n_roads = cm.n_lanes, len(cm.road_ids)
+    t.n_lanepoints, t.n_shape_pts, t.n_segments = cm.n_lanepoints, len(cm.shape_x), len(cm.seg_lane)
+    for name, dt in _MAP_ARRAYS:
+        arr = np.ascontiguousarray(getattr(cm, name), dtype=dt)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=dt)
+        keep.append(arr)
+        setattr(t, name, arr.ctypes.data)
+    t.lpg_x0, t.lpg_y0, t.lpg_cell = float(cm.lpg_origin[0]), float(cm.lpg_origin[1]), float(cm.lpg_cell)
+    t.lpg_nx, t.lpg_ny = int(cm.lpg_dims[0]), int(cm.lpg_dims[1])
+    t.sg_x0, t.sg_y0, t.sg_cell = float(cm.sg_origin[0]), float(cm.sg_origin[1]), float(cm.sg_cell)
+    t.sg_nx, t.sg_ny = int(cm.sg_dims[0]), int(cm.sg_dims[1])
+    t.default_lane_width = float(cm.default_lane_width)
+    return t, keep
+
+
+class BatchedSim:
+    """One shard of environment instances resident on one GPU."""
+
+    def __init__(self, cm: CompiledMap, cfg: SimConfig, device: str = "cuda:0", spawns: Optional[np.ndarray] = None,
+                 spawn_episodes: int = 2, seed: int = 42, first_env: int = 0):
+        self.lib = nat.load_library()
+        if not torch.cuda.is_available():
+            raise nat.NativeLibraryError("no ROCm device visible: the smarts_amd hot path runs on the GPU only")
+        self.cm = cm
+        self.cfg = cfg
+        self.device = torch.device(device)
+        E, N = cfg.num_envs, cfg.num_vehicles
+        self.E, self.N = E, N
+        dev = self.device
+        idx = self.device.index if self.device.index is not None else 0
+
+        c = nat.SmxConfig()
+        c.num_envs, c.num_vehicles, c.dt = E, N, cfg.dt
+        c.sensors, c.done_criteria = cfg.sensors_mask(), cfg.done_mask()
+        c.wp_lookahead, c.wp_paths, c.wp_len = cfg.wp_lookahead, cfg.wp_paths, cfg.wp_len
+        c.nb_max = cfg.nb_max
+        c.nb_radius = -1.0 if cfg.nb_radius is None else float(cfg.nb_radius)
+        c.max_episode_steps = cfg.max_episode_steps or 0
+        c.not_moving_time, c.not_moving_distance = cfg.not_moving_time, cfg.not_moving_distance
+        c.auto_reset = 1 if cfg.auto_reset else 0
+        c.reset_elapsed_steps = cfg.reset_elapsed_steps()
+        self._c = c
+        self.handle = C.c_void_p()
+        rc = self.lib.smx_create(C.byref(c), idx, C.byref(self.handle))
+        nat.check(self.lib, self.handle, rc, "smx_create")
+        tables, keep = map_tables_struct(cm)
+        nat.check(self.lib, self.handle, self.lib.smx_load_map(self.handle, C.byref(tables)), "smx_load_map")
+        del keep
+
+        # ---- state ----
+        T = E * N
+        self.state = torch.zeros((nat.S_COUNT, E, N), dtype=torch.float64, device=dev)
+        self.flags = torch.zeros((E, N), dtype=torch.int32, device=dev)
+        self.steps = torch.zeros((E, N), dtype=torch.int32, device=dev)
+        self.env_ticks = torch.zeros((E,), dtype=torch.int32, device=dev)
+        self.env_done_count = torch.zeros((E,), dtype=torch.int32, device=dev)
+        self.env_episode = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        need_ring = cfg.track_driven_path or cfg.done_not_moving
+        self.driven_path = torch.zeros((T, nat.DRIVEN_PATH_LEN), dtype=torch.float64, device=dev) if need_ring else None
+        st = nat.SmxState()
+        st.f64, st.flags, st.steps = self.state.data_ptr(), self.flags.data_ptr(), self.steps.data_ptr()
+        st.env_ticks, st.env_done_count = self.env_ticks.data_ptr(), self.env_done_count.data_ptr()
+        st.env_episode = self.env_episode.data_ptr()
+        st.driven_path = self.driven_path.data_ptr() if need_ring else None
+        self._st = st
+
+        # ---- spawns ----
+        if spawns is None:
+            spawns = make_spawns(cm, E, N, episodes=spawn_episodes, seed=seed, first_env=first_env)
+        spawns = np.ascontiguousarray(spawns, dtype=np.float64)
+        assert spawns.ndim == 3 and spawns.shape[1:] == (T, 4), spawns.shape
+        self.spawns = torch.from_numpy(spawns).to(dev)
+        sp = nat.SmxSpawns()
+        sp.episodes, sp.pose = int(spawns.shape[0]), self.spawns.data_ptr()
+        self._sp = sp
+
+        # ---- outputs (dense StdObs layout, format_obs.py:313-373) ----
+        o: Dict[str, torch.Tensor] = {}
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        o["ego_pos"] = z((E, N, 3), torch.float64)
+        o["ego_f32"] = z((E, N, nat.EGO_F32_COUNT), torch.float32)
+        o["ego_lane"] = z((E, N, 2), torch.int16)
+        o["events"] = z((E, N, nat.EV_COUNT), torch.uint8)
+        o["reward"] = z((E, N), torch.float64)
+        o["dist"] = z((E, N), torch.float64)
+        o["done"] = z((E, N), torch.uint8)
+        o["active"] = z((E, N), torch.uint8)
+        o["env_done"] = z((E,), torch.uint8)
+        if cfg.waypoints:
+            P, W = cfg.wp_paths, cfg.wp_len
+            o["wp_pos"] = z((E, N, P, W, 3), torch.float64)
+            o["wp_heading"] = z((E, N, P, W), torch.float32)
+            o["wp_lane_width"] = z((E, N, P, W), torch.float32)
+            o["wp_speed_limit"] = z((E, N, P, W), torch.float32)
+            o["wp_lane_index"] = z((E, N, P, W), torch.int8)
+            o["wp_lane_id"] = z((E, N, P, W), torch.int16)
+            o["wp_count"] = z((E, N, P + 1), torch.uint8)
+        if cfg.neighbors:
+            K = cfg.nb_max
+            o["nb_pos"] = z((E, N, K, 3), torch.float64)
+            o["nb_box"] = z((E, N, K, 3), torch.float32)
+            o["nb_heading"] = z((E, N, K), torch.float32)
+            o["nb_speed"] = z((E, N, K), torch.float32)
+            o["nb_lane_index"] = z((E, N, K), torch.int8)
+            o["nb_lane_id"] = z((E, N, K), torch.int16)
+            o["nb_slot"] = z((E, N, K), torch.int8)
+            o["nb_count"] = z((E, N), torch.uint8)
+        self.out = o
+        so = nat.SmxOutputs()
+        for name in nat.OUTPUT_FIELDS:
+            setattr(so, name, o[name].data_ptr() if name in o else None)
+        self._out = so
+        self._stream = None
+        self._was_reset = False
+
+    # ------------------------------------------------------------------
+    def _stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def output_bytes_per_agent_step(self) -> int:
+        """Bytes of observation/reward/done written per agent-step (dense layout)."""
+        per = 0
+        for name, t in self.out.items():
+            if name in ("env_done",):
+                continue
+            per += t[0, 0].numel() * t.element_size()
+        return per
+
+    def state_bytes_per_agent_step(self) -> int:
+        return nat.S_COUNT * 8 + 4 + 4
+
+    def reset(self, env_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        mask_ptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert env_mask.shape == (self.E,)
+            mask_ptr = env_mask.data_ptr()
+        rc = self.lib.smx_reset(self.handle, mask_ptr, C.byref(self._st), C.byref(self._sp), C.byref(self._out),
+                                self._stream_ptr())
+        nat.check(self.lib, self.handle, rc, "smx_reset")
+        self._was_reset = True
+        return self.out
+
+    def step(self, actions: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if not self._was_reset:
+            raise RuntimeError("step() before reset()")  # SMARTSNotSetupError (smarts.py:207-208)
+        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        assert actions.shape == (self.E, self.N), actions.shape
+        rc = self.lib.smx_step(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
+                               C.byref(self._out), self._stream_ptr())
+        nat.check(self.lib, self.handle, rc, "smx_step")
+        return self.out
+
+    def set_timing(self, enabled: bool):
+        nat.check(self.lib, self.handle, self.lib.smx_set_timing(self.handle, 1 if enabled else 0), "smx_set_timing")
+
+    def last_step_ms(self) -> float:
+        ms = C.c_float()
+        nat.check(self.lib, self.handle, self.lib.smx_last_step_ms(self.handle, C.byref(ms)), "smx_last_step_ms")
+        return float(ms.value)
+
+    def sync(self):
+        nat.check(self.lib, self.handle, self.lib.smx_sync(self.handle, self._stream_ptr()), "smx_sync")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.smx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # smarts.py:711-721
+        try:
+            self.close()
+        except Exception:
+            pass

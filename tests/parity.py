@@ -1,0 +1,162 @@
+"""Shared helpers for parity tests: run the oracle on the same spawns/actions and pack its
+ragged Python observations into the device's dense layout (include/smx.h)."""
+import numpy as np
+
+from oracle.road_network import ORoadNetwork
+from oracle.sim import AgentConfig, OracleEnv
+from smarts_amd import _native as nat
+
+
+def oracle_config(cfg):
+    return AgentConfig(
+        waypoints_lookahead=cfg.wp_lookahead if cfg.waypoints else None,
+        neighborhood_radius=cfg.nb_radius,
+        neighborhood_enabled=cfg.neighbors,
+        accelerometer=cfg.accelerometer,
+        max_episode_steps=cfg.max_episode_steps,
+        done_collision=cfg.done_collision,
+        done_off_road=cfg.done_off_road,
+        done_off_route=cfg.done_off_route,
+        done_on_shoulder=cfg.done_on_shoulder,
+        done_wrong_way=cfg.done_wrong_way,
+        done_not_moving=cfg.done_not_moving,
+        not_moving_time=cfg.not_moving_time,
+        not_moving_distance=cfg.not_moving_distance,
+    )
+
+
+def empty_dense(cfg, n):
+    P, W, K = cfg.wp_paths, cfg.wp_len, cfg.nb_max
+    d = dict(
+        ego_pos=np.zeros((n, 3)), ego_f32=np.zeros((n, nat.EGO_F32_COUNT), np.float32),
+        ego_lane=np.full((n, 2), -1, np.int16), events=np.zeros((n, nat.EV_COUNT), np.uint8),
+        reward=np.zeros(n), dist=np.zeros(n), done=np.zeros(n, np.uint8), active=np.zeros(n, np.uint8),
+    )
+    if cfg.waypoints:
+        d.update(
+            wp_pos=np.zeros((n, P, W, 3)), wp_heading=np.zeros((n, P, W), np.float32),
+            wp_lane_width=np.zeros((n, P, W), np.float32), wp_speed_limit=np.zeros((n, P, W), np.float32),
+            wp_lane_index=np.zeros((n, P, W), np.int8), wp_lane_id=np.full((n, P, W), -1, np.int16),
+            wp_count=np.zeros((n, P + 1), np.uint8),
+        )
+    if cfg.neighbors:
+        d.update(
+            nb_pos=np.zeros((n, K, 3)), nb_box=np.zeros((n, K, 3), np.float32), nb_heading=np.zeros((n, K), np.float32),
+            nb_speed=np.zeros((n, K), np.float32), nb_lane_index=np.zeros((n, K), np.int8),
+            nb_lane_id=np.full((n, K), -1, np.int16), nb_slot=np.full((n, K), -1, np.int8),
+            nb_count=np.zeros(n, np.uint8),
+        )
+    return d
+
+
+def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
+    """Oracle observation dicts of one env -> dense arrays (rows of absent agents stay zero)."""
+    d = empty_dense(cfg, n)
+    E = nat.EGO
+    for i, o in obs.items():
+        e = o["ego"]
+        d["ego_pos"][i] = e["position"]
+        f = d["ego_f32"][i]
+        f[E["HEADING"]] = e["heading"]
+        f[E["SPEED"]] = e["speed"]
+        f[E["STEERING"]] = e["steering"]
+        f[E["YAW_RATE"]] = e["yaw_rate"]
+        f[E["LIN_VEL"]:E["LIN_VEL"] + 3] = e["linear_velocity"]
+        f[E["ANG_VEL"]:E["ANG_VEL"] + 3] = e["angular_velocity"]
+        if "linear_acceleration" in e:
+            f[E["LIN_ACC"]:E["LIN_ACC"] + 3] = e["linear_acceleration"]
+            f[E["ANG_ACC"]:E["ANG_ACC"] + 3] = e["angular_acceleration"]
+            f[E["LIN_JERK"]:E["LIN_JERK"] + 3] = e["linear_jerk"]
+            f[E["ANG_JERK"]:E["ANG_JERK"] + 3] = e["angular_jerk"]
+        f[E["BOX"]:E["BOX"] + 3] = e["box"]
+        d["ego_lane"][i, 0] = lane_no[e["lane_id"]] if e["lane_id"] is not None else -1
+        d["ego_lane"][i, 1] = e["lane_index"] if e["lane_index"] is not None else -1
+        ev = o["events"]
+        d["events"][i] = [
+            len(ev["collisions"]) > 0, ev["off_road"], ev["off_route"], ev["on_shoulder"], ev["wrong_way"],
+            ev["not_moving"], ev["reached_goal"], ev["reached_max_episode_steps"], ev["agents_alive_done"],
+        ]
+        d["dist"][i] = o["distance_travelled"]
+        d["active"][i] = 1
+        if rewards is not None:
+            d["reward"][i] = rewards[i]
+        if dones is not None:
+            d["done"][i] = dones[i]
+            d["active"][i] = 0 if dones[i] else 1
+        if cfg.waypoints and o["waypoint_paths"] is not None:
+            paths = o["waypoint_paths"]
+            d["wp_count"][i, 0] = min(len(paths), 255)
+            for p, path in enumerate(paths[: cfg.wp_paths]):
+                d["wp_count"][i, 1 + p] = min(len(path), cfg.wp_len)
+                for w, wp in enumerate(path[: cfg.wp_len]):
+                    d["wp_pos"][i, p, w, :2] = wp.pos
+                    d["wp_heading"][i, p, w] = wp.heading
+                    d["wp_lane_width"][i, p, w] = wp.lane_width
+                    d["wp_speed_limit"][i, p, w] = wp.speed_limit
+                    d["wp_lane_index"][i, p, w] = wp.lane_index
+                    d["wp_lane_id"][i, p, w] = lane_no[wp.lane_id]
+        if cfg.neighbors:
+            nvs = o["neighbors"]
+            d["nb_count"][i] = min(len(nvs), 255)
+            for k, nv in enumerate(nvs[: cfg.nb_max]):
+                d["nb_pos"][i, k] = nv["position"]
+                d["nb_box"][i, k] = nv["box"]
+                d["nb_heading"][i, k] = nv["heading"]
+                d["nb_speed"][i, k] = nv["speed"]
+                d["nb_lane_index"][i, k] = nv["lane_index"] if nv["lane_index"] is not None else -1
+                d["nb_lane_id"][i, k] = lane_no[nv["lane_id"]] if nv["lane_id"] is not None else -1
+                d["nb_slot"][i, k] = nv["slot"]
+    return d
+
+
+INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
+            "nb_lane_id", "nb_slot", "nb_count"]
+
+
+def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
+    """Bit-exact on integer/flag arrays, tolerance on floats.  Returns list of mismatch strings."""
+    bad = []
+    for k, a in ora.items():
+        b = dev[k]
+        if k in INT_KEYS:
+            if not np.array_equal(a, b):
+                idx = np.argwhere(a != b)[:4]
+                bad.append(f"{where}{k}: {len(np.argwhere(a != b))} int mismatches, first {idx.tolist()} "
+                           f"oracle={a[tuple(idx[0])]} dev={b[tuple(idx[0])]}")
+        else:
+            tol = tol32 if a.dtype == np.float32 else tol64
+            err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+            if a.dtype == np.float32:
+                err = err / np.maximum(1.0, np.abs(a.astype(np.float64)))
+            if err.size and err.max() > tol:
+                idx = np.unravel_index(np.argmax(err), err.shape)
+                bad.append(f"{where}{k}: max err {err.max():.3e} at {idx} oracle={a[idx]} dev={b[idx]}")
+    return bad
+
+
+class OracleBatch:
+    """E independent oracle envs driven with the same spawns/actions as the device."""
+
+    def __init__(self, net, cm, cfg, spawns_ep0):
+        self.cfg = cfg
+        self.road_map = ORoadNetwork(net, lanepoint_spacing=cm.lanepoint_spacing)
+        self.lane_no = {lid: i for i, lid in enumerate(cm.lane_ids)}
+        self.N = cfg.num_vehicles
+        ocfg = oracle_config(cfg)
+        self.envs = [
+            OracleEnv(self.road_map, spawns_ep0[e * self.N:(e + 1) * self.N], [ocfg] * self.N, dt=cfg.dt)
+            for e in range(cfg.num_envs)
+        ]
+
+    def _stack(self, parts):
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+    def reset_observe(self):
+        return self._stack([pack(self.cfg, self.lane_no, self.N, env.reset_observe()) for env in self.envs])
+
+    def step(self, actions):
+        parts = []
+        for e, env in enumerate(self.envs):
+            obs, rew, dones = env.step(list(actions[e]))
+            parts.append(pack(self.cfg, self.lane_no, self.N, obs, rew, dones))
+        return self._stack(parts)
