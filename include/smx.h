@@ -251,6 +251,12 @@ int smx_sync(smx_handle h, void* hip_stream);
 int smx_last_step_ms(smx_handle h, float* ms);
 int smx_set_timing(smx_handle h, int enabled);
 const char* smx_last_error(smx_handle h);
+/* sizeof() of the ABI structs as compiled (0 config, 1 map tables, 2 state, 3 spawns, 4 outputs):
+ * lets a foreign-language binding verify its mirror of the layouts. */
+uint64_t smx_struct_size(int which);
+/* Lateral gains of the lane-following controller for target_speed > 0
+ * (lane_following_controller.py:420-430); defaults are the sedan's clip bounds (0.04, 3.4). */
+int smx_set_controller_gains(smx_handle h, double heading_gain, double lateral_gain);
 const char* smx_version(void);
 void smx_destroy(smx_handle h);
 

@@ -272,7 +272,18 @@ def _kd(lps):
 
 
 class OLanePoints:
-    """``LanePoints`` (lanepoints.py:73-102, 517-692)."""
+    """``LanePoints`` (lanepoints.py:73-102, 517-692).
+
+    ``tie_rule``: the reference hands ties between *exactly equidistant* lanepoints
+    (coincident lane-end / lane-start points on collinear lanes) to scipy's KD-tree,
+    whose order among equal distances is an artefact of its heap and tree layout.
+    ``"kdtree"`` keeps that behaviour (used to pin this restatement against the
+    reference's own outputs); ``"index"`` orders equal distances by lanepoint index
+    in the reference's global lanepoint order, which is the rule the device kernels
+    implement (DESIGN.md "Deviations").  The two rules differ only on exact ties.
+    """
+
+    tie_rule = "index"
 
     def __init__(self, omap, spacing):
         self.linked = interpolate_shape_lanepoints(shape_lanepoints(omap), spacing)
@@ -285,13 +296,29 @@ class OLanePoints:
         self.tree_by_lane = {k: _kd(v) for k, v in self.by_lane.items()}
         self.tree_by_road = {k: _kd(v) for k, v in self.by_road.items()}
 
-    @staticmethod
-    def _closest_batched(points, lps, tree, k=1):
+    @classmethod
+    def _closest_batched(cls, points, lps, tree, k=1):
         # lanepoints.py:517-524
         p2ds = np.array([np.array(p[:2]) for p in points])
-        _, closest_indices = tree.query(p2ds, k=min(k, len(lps)))
-        closest_indices = np.atleast_2d(closest_indices)
-        return [[lps[idx] for idx in idxs] for idxs in closest_indices]
+        kk = min(k, len(lps))
+        if cls.tie_rule == "kdtree":
+            _, closest_indices = tree.query(p2ds, k=kk)
+            closest_indices = np.atleast_2d(closest_indices)
+            return [[lps[idx] for idx in idxs] for idxs in closest_indices]
+        # same neighbours, equal distances ordered by global lanepoint index
+        extra = min(len(lps), kk + 8)
+        _, cand = tree.query(p2ds, k=extra)
+        cand = np.asarray(cand).reshape(len(p2ds), -1)
+        out = []
+        for p, idxs in zip(p2ds, cand):
+            keyed = []
+            for i in idxs:
+                q = lps[i].pos
+                dx, dy = q[0] - p[0], q[1] - p[1]
+                keyed.append((dx * dx + dy * dy, lps[i].idx, i))
+            keyed.sort()
+            out.append([lps[i] for _, _, i in keyed[:kk]])
+        return out
 
     @staticmethod
     def _closest_with_pose(pos2d, heading, lps, tree, within_radius, k=10):
@@ -302,7 +329,7 @@ class OLanePoints:
             d = l.pos[:2] - pos2d
             return np.dot(d, d)
 
-        cands = sorted(cands, key=sq)
+        cands = sorted(cands, key=sq)  # stable: equal distances keep the order above
         if within_radius is not None:
             radius_sq = within_radius * within_radius
             cands = [l for i, l in enumerate(cands) if sq(l) <= radius_sq or i == 0]

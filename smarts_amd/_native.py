@@ -88,7 +88,7 @@ class SmxOutputs(C.Structure):
 
 EXPORTS = [
     "smx_create", "smx_load_map", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
-    "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains",
+    "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -138,6 +138,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_version.restype = C.c_char_p
     lib.smx_destroy.argtypes = [h]
     lib.smx_destroy.restype = None
+    lib.smx_struct_size.argtypes = [C.c_int]
+    lib.smx_struct_size.restype = C.c_uint64
+    for which, mirror in enumerate((SmxConfig, SmxMapTables, SmxState, SmxSpawns, SmxOutputs)):
+        if lib.smx_struct_size(which) != C.sizeof(mirror):
+            raise NativeLibraryError(
+                f"ABI mismatch: {mirror.__name__} is {C.sizeof(mirror)} bytes here, "
+                f"{lib.smx_struct_size(which)} in {path} (stale build?)"
+            )
     _lib = lib
     return lib
 

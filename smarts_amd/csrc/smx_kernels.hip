@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
         a.out.active[gid] = done ? 0 : 1;
       } else {
         zero_outputs(a, gid);
-        a.out.dist[gid] = SF(SMX_S_DIST);
+        a.out.dist[gid] = 0.0;
         a.out.done[gid] = 0;
         a.out.active[gid] = 0;
       }
@@ -861,6 +861,17 @@ static int fail(smx_handle h, int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; }
+
+extern "C" uint64_t smx_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(smx_config);
+    case 1: return sizeof(smx_map_tables);
+    case 2: return sizeof(smx_state);
+    case 3: return sizeof(smx_spawns);
+    case 4: return sizeof(smx_outputs);
+    default: return 0;
+  }
+}
 
 extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if (!cfg || !out) return SMX_ERR_INVALID;

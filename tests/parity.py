@@ -160,3 +160,40 @@ class OracleBatch:
             obs, rew, dones = env.step(list(actions[e]))
             parts.append(pack(self.cfg, self.lane_no, self.N, obs, rew, dones))
         return self._stack(parts)
+
+
+def sync_oracle_from_device(ob: "OracleBatch", sim):
+    """Teacher forcing: overwrite every oracle vehicle's continuous state with the device's, so
+    that each tick is compared as a single step from identical state (closed-loop lane following
+    is bang-bang and amplifies last-ulp libm differences across ticks)."""
+    import torch
+
+    torch.cuda.synchronize()
+    st = sim.state.cpu().numpy().reshape(nat.S_COUNT, -1)
+    flags = sim.flags.cpu().numpy().reshape(-1)
+    S = nat.S
+    lane_ids = sim.cm.lane_ids
+    for e, env in enumerate(ob.envs):
+        for i, ag in enumerate(env.agents):
+            g = e * ob.N + i
+            b, c = ag.body, ag.ctrl
+            b.x, b.y, b.heading = st[S["X"], g], st[S["Y"], g], st[S["HEADING"], g]
+            b.u, b.v, b.yaw_rate_z, b.delta = st[S["U"], g], st[S["V"], g], st[S["R"], g], st[S["DELTA"], g]
+            c.lateral_integral_error = st[S["LAT_INT"], g]
+            c.integral_speed_error = st[S["SPD_INT"], g]
+            c.steering_state = st[S["STEER"], g]
+            c.throttle_state = st[S["THROTTLE"], g]
+            c.speed_error = st[S["SPD_ERR"], g]
+            if flags[g] & nat.F_MCL_SET:
+                c.min_curvature_location = (st[S["MCL_X"], g], st[S["MCL_Y"], g])
+            ag.dist_travelled = st[S["DIST"], g]
+            if ag.wps_for_distance:
+                w = ag.wps_for_distance[-1]
+                w.pos = np.array([st[S["TRIP_X"], g], st[S["TRIP_Y"], g]])
+                w.heading = st[S["TRIP_H"], g]
+            if len(ag.linear_velocities) >= 1:
+                ag.linear_velocities[-1] = np.array([st[S["LV0_LONG"], g], st[S["LV0_LAT"], g], 0.0])
+                ag.angular_velocities[-1] = np.array([0.0, 0.0, st[S["AV0_Z"], g]])
+            if len(ag.linear_velocities) >= 2:
+                ag.linear_velocities[-2] = np.array([st[S["LV1_LONG"], g], st[S["LV1_LAT"], g], 0.0])
+                ag.angular_velocities[-2] = np.array([0.0, 0.0, st[S["AV1_Z"], g]])

@@ -1,0 +1,120 @@
+"""Host-side product logic (no GPU): map compiler tables, controller gain constants, spawn
+table, and the C-ABI surface of the built library."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+MAP_NAMES = ["loop", "4lane", "minicity"]
+
+
+@pytest.mark.parametrize("name", MAP_NAMES)
+def test_map_compiler_lanepoints_match_reference(name, compiled_maps):
+    """The compiled lanepoint table equals the reference's LanePoints.from_sumo output
+    (fixture from tests/golden/gen_golden.py) bit for bit, in the reference's order."""
+    cm = compiled_maps(name)
+    g = np.load(os.path.join(GOLDEN, f"lanepoints_{name}.npz"))
+    n = len(g["x"])
+    total = int(g["total"]) if "total" in g else n
+    assert cm.n_lanepoints == total
+    assert np.array_equal(cm.lp_x[:n], g["x"]) and np.array_equal(cm.lp_y[:n], g["y"])
+    assert np.array_equal(cm.lp_heading[:n], g["heading"])
+    assert np.array_equal(cm.lp_inferred[:n], g["inferred"])
+    gl = list(g["lane_ids"])
+    assert all(cm.lane_ids[cm.lp_lane[i]] == gl[g["lane"][i]] for i in range(n))
+    assert np.array_equal(cm.lp_next_off[: n + 1], g["next_off"])
+    assert np.array_equal(cm.lp_next_idx[: g["next_off"][n]], g["next_idx"])
+    if "sum_x" in g:
+        assert cm.lp_x.sum() == float(g["sum_x"]) and cm.lp_heading.sum() == float(g["sum_heading"])
+
+
+@pytest.mark.parametrize("name", MAP_NAMES)
+def test_grids_cover_every_item(name, compiled_maps):
+    cm = compiled_maps(name)
+    # every lanepoint sits in exactly the cell its coordinates hash to
+    cx = np.floor((cm.lp_x - cm.lpg_origin[0]) / cm.lpg_cell).astype(int)
+    cy = np.floor((cm.lp_y - cm.lpg_origin[1]) / cm.lpg_cell).astype(int)
+    assert (cx >= 0).all() and (cx < cm.lpg_dims[0]).all() and (cy >= 0).all() and (cy < cm.lpg_dims[1]).all()
+    cell = cy * cm.lpg_dims[0] + cx
+    assert len(cm.lpg_idx) == cm.n_lanepoints
+    for c in np.unique(cell)[:200]:
+        members = set(cm.lpg_idx[cm.lpg_off[c]: cm.lpg_off[c + 1]].tolist())
+        assert members == set(np.nonzero(cell == c)[0].tolist())
+    # every segment is listed in every cell its bounding box touches
+    assert set(cm.sg_idx.tolist()) == set(range(len(cm.seg_lane)))
+    assert cm.max_fanout <= 15  # BranchState packs 4 bits per level
+
+
+def test_lateral_gains_saturate_at_clip_bounds():
+    """lane_following_controller.py:420-430: for the sedan and every Lane-space target speed the
+    pole-placement gains fall outside the clip window, so the kernels use the bounds as constants."""
+    from oracle.controller import lateral_gains
+
+    for ts in (15, 12.5, 15.0):
+        hg, lg = lateral_gains(ts, 3.68 / 2, 2356.0, 2681.95008628, 100000.0)
+        assert (hg, lg) == (0.04, 3.4)
+    assert lateral_gains(0, 3.68 / 2, 2356.0, 2681.95008628, 100000.0) == (0.01, 0.36)
+
+
+def test_spawn_table(compiled_maps):
+    from smarts_amd.engine import make_spawns
+
+    cm = compiled_maps("loop")
+    sp = make_spawns(cm, 3, 8, episodes=2, seed=42)
+    assert sp.shape == (2, 24, 4)
+    # env e uses PCG64(seed + e): shifting first_env reproduces the same rows (shard independence)
+    sp2 = make_spawns(cm, 1, 8, episodes=2, seed=42, first_env=2)
+    assert np.array_equal(sp[:, 16:24], sp2)
+    # speed = lane speed limit, vehicles on one lane at least 8 m apart along it
+    assert np.allclose(sp[..., 3], 16.67)
+    d = np.linalg.norm(sp[0, :8, None, :2] - sp[0, None, :8, :2], axis=-1) + np.eye(8) * 100
+    assert d.min() > 3.0
+
+
+def test_library_exports_every_declared_symbol():
+    """include/smx.h <-> libsmarts_mi355x.so: every declared entry point is exported."""
+    from smarts_amd import _native as nat
+    from smarts_amd import build
+
+    lib_path = build.build()
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, "include", "smx.h")).read()
+    declared = set(re.findall(r"\b(smx_[a-z_]+)\s*\(", header))
+    assert {"smx_create", "smx_load_map", "smx_reset", "smx_step", "smx_destroy"} <= declared
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in smx.h but not exported"
+    for sym in nat.EXPORTS:
+        assert hasattr(lib, sym)
+    lib.smx_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.smx_version()
+    # the ctypes mirrors have the sizes the library was compiled with
+    lib.smx_struct_size.restype = ctypes.c_uint64
+    for which, mirror in enumerate((nat.SmxConfig, nat.SmxMapTables, nat.SmxState, nat.SmxSpawns, nat.SmxOutputs)):
+        assert lib.smx_struct_size(which) == ctypes.sizeof(mirror), mirror.__name__
+    nat.load_library(lib_path)  # runs the same check and binds the prototypes
+
+
+def test_no_cpu_fallback(compiled_maps):
+    """Without a GPU the product path refuses to run (it must not route through the oracle)."""
+    import torch
+
+    from smarts_amd import _native as nat
+    from smarts_amd.engine import BatchedSim, SimConfig
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nat.NativeLibraryError):
+        BatchedSim(compiled_maps("loop"), SimConfig(num_envs=1, num_vehicles=2))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "smarts_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
