@@ -246,10 +246,13 @@ int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, co
 int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
              const smx_outputs* out, void* hip_stream);
 int smx_sync(smx_handle h, void* hip_stream);
-/* Device-side timing of the last smx_step on `hip_stream` (hipEvents recorded
- * around the launch); returns milliseconds in *ms. */
-int smx_last_step_ms(smx_handle h, float* ms);
+/* Device-side timing: while enabled, every smx_step is bracketed by a hipEvent pair recorded on
+ * the stream it is launched on (no synchronisation).  smx_read_step_ms waits for the recorded
+ * launches, writes their durations (milliseconds, oldest first, at most `max`) and clears the
+ * log; *n receives the count.  smx_last_step_ms is the single-launch convenience form. */
 int smx_set_timing(smx_handle h, int enabled);
+int smx_read_step_ms(smx_handle h, float* ms, int32_t max, int32_t* n);
+int smx_last_step_ms(smx_handle h, float* ms);
 const char* smx_last_error(smx_handle h);
 /* sizeof() of the ABI structs as compiled (0 config, 1 map tables, 2 state, 3 spawns, 4 outputs):
  * lets a foreign-language binding verify its mirror of the layouts. */

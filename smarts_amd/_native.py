@@ -88,7 +88,7 @@ class SmxOutputs(C.Structure):
 
 EXPORTS = [
     "smx_create", "smx_load_map", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
-    "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size",
+    "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -128,6 +128,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_sync.restype = C.c_int
     lib.smx_last_step_ms.argtypes = [h, C.POINTER(C.c_float)]
     lib.smx_last_step_ms.restype = C.c_int
+    lib.smx_read_step_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]
+    lib.smx_read_step_ms.restype = C.c_int
     lib.smx_set_timing.argtypes = [h, C.c_int]
     lib.smx_set_timing.restype = C.c_int
     lib.smx_set_controller_gains.argtypes = [h, _f64, _f64]

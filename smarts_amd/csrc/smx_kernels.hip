@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "smx_vehicle.h"
 
@@ -844,8 +845,8 @@ struct smx_handle_s {
   const double* lidar_rays;
   double heading_gain_pos, lateral_gain_pos;
   bool timing;
-  hipEvent_t ev0, ev1;
-  bool ev_valid, ev_recorded;
+  std::vector<hipEvent_t> ev_pool;  // pairs: [2*i] start, [2*i+1] stop
+  size_t ev_used;                   // pairs recorded since the last read
   std::string err;
 };
 
@@ -889,8 +890,7 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->heading_gain_pos = 0.04;
   h->lateral_gain_pos = 3.4;
   h->timing = false;
-  h->ev_valid = false;
-  h->ev_recorded = false;
+  h->ev_used = 0;
   *out = h;
   const smx_config& c = h->cfg;
   if (c.num_envs <= 0 || c.num_vehicles <= 0 || c.num_vehicles > SMX_BLOCK)
@@ -1076,19 +1076,22 @@ static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* 
   a.heading_gain_pos = h->heading_gain_pos;
   a.lateral_gain_pos = h->lateral_gain_pos;
   const int blocks = (h->cfg.num_envs + a.envs_per_block - 1) / a.envs_per_block;
-  if (h->timing && mode == 0) {
-    if (!h->ev_valid) {
-      SMX_HIP(hipEventCreate(&h->ev0));
-      SMX_HIP(hipEventCreate(&h->ev1));
-      h->ev_valid = true;
+  const bool timed = h->timing && mode == 0 && h->ev_used < 65536;
+  if (timed) {
+    if (h->ev_pool.size() < 2 * (h->ev_used + 1)) {
+      hipEvent_t e0, e1;
+      SMX_HIP(hipEventCreate(&e0));
+      SMX_HIP(hipEventCreate(&e1));
+      h->ev_pool.push_back(e0);
+      h->ev_pool.push_back(e1);
     }
-    SMX_HIP(hipEventRecord(h->ev0, stream));
+    SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used], stream));
   }
   hipLaunchKernelGGL(smx_tick_kernel, dim3(blocks), dim3(SMX_BLOCK), 0, stream, a, mode);
   SMX_HIP(hipGetLastError());
-  if (h->timing && mode == 0) {
-    SMX_HIP(hipEventRecord(h->ev1, stream));
-    h->ev_recorded = true;
+  if (timed) {
+    SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used + 1], stream));
+    h->ev_used += 1;
   }
   return SMX_OK;
 }
@@ -1115,11 +1118,26 @@ extern "C" int smx_set_timing(smx_handle h, int enabled) {
   return SMX_OK;
 }
 
+extern "C" int smx_read_step_ms(smx_handle h, float* ms, int32_t max, int32_t* n) {
+  if (!h || !ms || !n || max < 0) return SMX_ERR_INVALID;
+  int32_t count = 0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    SMX_HIP(hipEventSynchronize(h->ev_pool[2 * i + 1]));
+    float t = 0.f;
+    SMX_HIP(hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+    if (count < max) ms[count++] = t;
+  }
+  h->ev_used = 0;
+  *n = count;
+  return SMX_OK;
+}
+
 extern "C" int smx_last_step_ms(smx_handle h, float* ms) {
   if (!h || !ms) return SMX_ERR_INVALID;
-  if (!h->ev_recorded) return fail(h, SMX_ERR_STATE, "no timed step recorded (smx_set_timing(1) then smx_step)");
-  SMX_HIP(hipEventSynchronize(h->ev1));
-  SMX_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  if (h->ev_used == 0) return fail(h, SMX_ERR_STATE, "no timed step recorded (smx_set_timing(1) then smx_step)");
+  const size_t i = h->ev_used - 1;
+  SMX_HIP(hipEventSynchronize(h->ev_pool[2 * i + 1]));
+  SMX_HIP(hipEventElapsedTime(ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
   return SMX_OK;
 }
 
@@ -1128,9 +1146,6 @@ extern "C" const char* smx_last_error(smx_handle h) { return h ? h->err.c_str() 
 extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
-  if (h->ev_valid) {
-    (void)hipEventDestroy(h->ev0);
-    (void)hipEventDestroy(h->ev1);
-  }
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
 }

@@ -298,6 +298,14 @@ class BatchedSim:
         nat.check(self.lib, self.handle, self.lib.smx_last_step_ms(self.handle, C.byref(ms)), "smx_last_step_ms")
         return float(ms.value)
 
+    def read_step_ms(self, max_count: int = 65536) -> np.ndarray:
+        """Durations (ms) of the smx_step launches recorded since timing was enabled / last read."""
+        buf = (C.c_float * max_count)()
+        n = C.c_int32()
+        rc = self.lib.smx_read_step_ms(self.handle, buf, max_count, C.byref(n))
+        nat.check(self.lib, self.handle, rc, "smx_read_step_ms")
+        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+
     def sync(self):
         nat.check(self.lib, self.handle, self.lib.smx_sync(self.handle, self._stream_ptr()), "smx_sync")
 

@@ -1,0 +1,75 @@
+"""Multi-GPU: one process per GPU, each owning a contiguous range of environment instances.
+
+Environment instances are closed worlds (the reference runs each in its own process with its
+own seed ``seed + i``, ``smarts/env/wrappers/parallel_env.py:96-122,190-202``), so the data
+path has **no collective**: every rank steps its own shard.  The only exchange is the optional
+learner-side gather of the small per-tick ``{reward, done}`` block, done with
+``torch.distributed`` (backend ``"nccl"`` = RCCL over xGMI on ROCm; ``"gloo"`` on CPU in tests).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Env range ``[first_env, first_env + num_envs)`` of ``rank`` (SURVEY.md §8e partitioning)."""
+
+    total_envs: int
+    world_size: int
+    rank: int
+
+    @property
+    def first_env(self) -> int:
+        base, rem = divmod(self.total_envs, self.world_size)
+        return self.rank * base + min(self.rank, rem)
+
+    @property
+    def num_envs(self) -> int:
+        base, rem = divmod(self.total_envs, self.world_size)
+        return base + (1 if self.rank < rem else 0)
+
+    def seed_of(self, seed: int, local_env: int) -> int:
+        """ParallelEnv.seed: env i gets ``seed + i`` over the *global* index (parallel_env.py:199)."""
+        return seed + self.first_env + local_env
+
+
+def env_from_dist() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if absent)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend: Optional[str] = None):
+    rank, local_rank, world = env_from_dist()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class RewardDoneGather:
+    """Per-tick gather of the learner-facing block: reward (f32) and done (u8) of every agent of
+    every shard, packed as one f32 tensor ``[2, E_shard * N]`` so that it is ONE small collective
+    (C4: 4096 x 32 agents x 8 B = 1 MB node-wide).  Requires equal shard sizes (all_gather)."""
+
+    def __init__(self, num_envs: int, num_vehicles: int, device, world_size: int):
+        self.world = world_size
+        self.n = num_envs * num_vehicles
+        self.send = torch.zeros((2, self.n), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((world_size, 2, self.n), dtype=torch.float32, device=device)
+
+    def __call__(self, reward: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
+        self.send[0].copy_(reward.reshape(-1))
+        self.send[1].copy_(done.reshape(-1))
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+        else:
+            self.recv[0].copy_(self.send)
+        return self.recv

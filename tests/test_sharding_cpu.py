@@ -1,0 +1,71 @@
+"""N > 1 path on CPU: shard plan + the reward/done gather over gloo with world_size 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smarts_amd.sharding import RewardDoneGather, ShardPlan
+
+
+def test_shard_plan_partitions_every_env_once():
+    for total, world in [(4096, 8), (1024, 1), (10, 4), (7, 8)]:
+        seen = []
+        for r in range(world):
+            p = ShardPlan(total, world, r)
+            seen += list(range(p.first_env, p.first_env + p.num_envs))
+        assert seen == list(range(total))
+    # per-env seeds follow the global index like ParallelEnv.seed (parallel_env.py:190-202;
+    # test_parallel_env.py:104-112: seeds = first + i)
+    p = ShardPlan(4096, 8, 3)
+    assert p.first_env == 1536 and p.num_envs == 512
+    assert p.seed_of(42, 0) == 42 + 1536 and p.seed_of(42, 5) == 42 + 1541
+
+
+def test_spawns_are_shard_invariant(compiled_maps):
+    """A rank's spawn table equals the slice of the single-process table: sharding changes where an
+    env runs, not what it computes."""
+    from smarts_amd.engine import make_spawns
+
+    cm = compiled_maps("loop")
+    whole = make_spawns(cm, 8, 4, episodes=2, seed=42)
+    for r in range(2):
+        p = ShardPlan(8, 2, r)
+        part = make_spawns(cm, p.num_envs, 4, episodes=2, seed=42, first_env=p.first_env)
+        assert np.array_equal(part, whole[:, p.first_env * 4:(p.first_env + p.num_envs) * 4])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E, N = 3, 4
+    g = RewardDoneGather(E, N, "cpu", world)
+    reward = torch.arange(E * N, dtype=torch.float64).reshape(E, N) + 100 * rank
+    done = ((torch.arange(E * N) + rank) % 2).to(torch.uint8).reshape(E, N)
+    out = g(reward, done)
+    q.put((rank, out.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reward_done_gather_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        got = results[r]
+        assert got.shape == (2, 2, 12)
+        for src in range(world):
+            assert np.array_equal(got[src, 0], np.arange(12) + 100 * src)
+            assert np.array_equal(got[src, 1], (np.arange(12) + src) % 2)
