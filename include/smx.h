@@ -104,10 +104,36 @@ typedef struct smx_config {
   double lidar_max_distance;
 } smx_config;
 
-/* Host-side SoA map tables produced by smarts_amd.map_compiler.compile_map().
+/* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */
+typedef struct smx_lp_rec {   /* one lanepoint = one 64-byte line (LanePoint + LinkedLanePoint, lanepoints.py:46-70) */
+  double x, y, heading;       /* pose (heading as Pose.heading yields it, coordinates.py:394-403) */
+  double dirx, diry;          /* radians_to_vec(heading) (math.py:247-253), host libm */
+  int32_t lane;
+  int32_t next_off;           /* first successor record in succ_rec */
+  int32_t next0;              /* first successor lanepoint, -1 none */
+  uint16_t n_next;
+  uint8_t inferred;           /* LinkedLanePoint.is_inferred */
+  uint8_t flags;              /* bit 0: interpolated points down the chain have consecutive indices */
+  int32_t knot_next;          /* next non-inferred lanepoint following successor 0 */
+  int32_t knot_hops;          /* hops from here to knot_next */
+} smx_lp_rec;
+typedef struct smx_succ_rec { /* one entry of LinkedLanePoint.nexts */
+  int32_t idx;                /* the successor lanepoint */
+  int32_t lane;               /* its lane (route filter of lanepoints.py:666-683) */
+  int32_t knot;               /* first non-inferred lanepoint down that branch */
+  int32_t hops;               /* hops from the branching point to it */
+} smx_succ_rec;
+typedef struct smx_pt_rec { double x, y; int32_t idx, lane; } smx_pt_rec;   /* lanepoint grid member */
+typedef struct smx_seg_rec {  /* centre-line segment grid member */
+  double x1, y1, x2, y2;
+  double thr;                 /* 0.5 * lane width + 0.1 (road_with_point, sumo_road_network.py:707) */
+  int32_t lane, pad;
+} smx_seg_rec;
+
+/* Host-side map tables produced by smarts_amd.map_compiler (compile_map + pack_tables).
  * smx_load_map copies them to the device.  Lane order = sumolib _allLanes order. */
 typedef struct smx_map_tables {
-  int32_t n_lanes, n_roads, n_lanepoints, n_shape_pts, n_segments;
+  int32_t n_lanes, n_roads, n_lanepoints, n_shape_pts, n_succ;
   const int32_t* lane_road;
   const int32_t* lane_index;
   const double* lane_width;
@@ -118,30 +144,21 @@ typedef struct smx_map_tables {
   const double* shape_x;
   const double* shape_y;
   const int32_t* lane_out_off;   /* n_lanes + 1 */
-  const int32_t* lane_out_idx;
+  const int32_t* lane_out_idx;   /* Lane.outgoing_lanes (sumo_road_network.py:350-358) */
   const int32_t* road_lane_off;  /* n_roads + 1 */
   const int32_t* road_lanes;
   const uint8_t* road_is_junction;
   const int32_t* road_out_road;
-  const double* lp_x;
-  const double* lp_y;
-  const double* lp_heading;
-  const double* lp_dirx;
-  const double* lp_diry;
-  const int32_t* lp_lane;
-  const uint8_t* lp_inferred;
-  const int32_t* lp_next_off;    /* n_lanepoints + 1 */
-  const int32_t* lp_next_idx;
-  double lpg_x0, lpg_y0, lpg_cell;
+  const smx_lp_rec* lp_rec;      /* n_lanepoints, the reference's global lanepoint order */
+  const smx_succ_rec* succ_rec;  /* n_succ */
+  double lpg_x0, lpg_y0, lpg_cell; /* uniform grid over lanepoints (replaces scipy KD-trees) */
   int32_t lpg_nx, lpg_ny;
   const int32_t* lpg_off;        /* lpg_nx * lpg_ny + 1 */
-  const int32_t* lpg_idx;
-  const int32_t* seg_lane;
-  const int32_t* seg_v0;
-  double sg_x0, sg_y0, sg_cell;
+  const smx_pt_rec* lpg_pts;     /* members by value, contiguous per cell */
+  double sg_x0, sg_y0, sg_cell;  /* uniform grid over centre-line segments (replaces the rtree) */
   int32_t sg_nx, sg_ny;
   const int32_t* sg_off;         /* sg_nx * sg_ny + 1 */
-  const int32_t* sg_idx;
+  const smx_seg_rec* sg_rec;
   double default_lane_width;     /* sumo_road_network.py:80 */
 } smx_map_tables;
 
@@ -176,7 +193,12 @@ typedef struct smx_state {
   int32_t* env_episode;    /* [E] episodes completed (indexes the spawn table) */
   double* driven_path; /* [E*N][SMX_DRIVEN_PATH_LEN] ring of step lengths, or NULL
                          when SMX_DONE_NOT_MOVING tracking is not wanted        */
+  int32_t* seed_cache; /* [SMX_SEED_COUNT][E*N]: start road / route filter / start lanepoints
+                          found by the last observation at the vehicle's current pose; the
+                          next tick's controller queries the map at that same pose
+                          (lane_following_controller.py:96-98) and reuses them     */
 } smx_state;
+#define SMX_SEED_COUNT 9 /* road, filter n, filter roads x2, lane count, start lanepoint x4 */
 
 /* Spawn table: episode k of env e starts from row (k mod episodes).
  * x, y = vehicle centre, heading in reference convention, speed m/s. */

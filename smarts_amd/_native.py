@@ -29,6 +29,7 @@ S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
 F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT = 1, 2, 4, 3
 DRIVEN_PATH_LEN = 500
+SEED_COUNT = 9
 EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,
            ANG_JERK=19, BOX=22)
 EGO_F32_COUNT = 25
@@ -51,23 +52,22 @@ class SmxConfig(C.Structure):
 
 class SmxMapTables(C.Structure):
     _fields_ = [
-        ("n_lanes", _i32), ("n_roads", _i32), ("n_lanepoints", _i32), ("n_shape_pts", _i32), ("n_segments", _i32),
+        ("n_lanes", _i32), ("n_roads", _i32), ("n_lanepoints", _i32), ("n_shape_pts", _i32), ("n_succ", _i32),
         ("lane_road", _p), ("lane_index", _p), ("lane_width", _p), ("lane_speed", _p), ("lane_length", _p),
         ("lane_in_junction", _p), ("lane_shape_off", _p), ("shape_x", _p), ("shape_y", _p),
         ("lane_out_off", _p), ("lane_out_idx", _p), ("road_lane_off", _p), ("road_lanes", _p),
         ("road_is_junction", _p), ("road_out_road", _p),
-        ("lp_x", _p), ("lp_y", _p), ("lp_heading", _p), ("lp_dirx", _p), ("lp_diry", _p), ("lp_lane", _p),
-        ("lp_inferred", _p), ("lp_next_off", _p), ("lp_next_idx", _p),
+        ("lp_rec", _p), ("succ_rec", _p),
         ("lpg_x0", _f64), ("lpg_y0", _f64), ("lpg_cell", _f64), ("lpg_nx", _i32), ("lpg_ny", _i32),
-        ("lpg_off", _p), ("lpg_idx", _p), ("seg_lane", _p), ("seg_v0", _p),
+        ("lpg_off", _p), ("lpg_pts", _p),
         ("sg_x0", _f64), ("sg_y0", _f64), ("sg_cell", _f64), ("sg_nx", _i32), ("sg_ny", _i32),
-        ("sg_off", _p), ("sg_idx", _p), ("default_lane_width", _f64),
+        ("sg_off", _p), ("sg_rec", _p), ("default_lane_width", _f64),
     ]
 
 
 class SmxState(C.Structure):
     _fields_ = [("f64", _p), ("flags", _p), ("steps", _p), ("env_ticks", _p), ("env_done_count", _p),
-                ("env_episode", _p), ("driven_path", _p)]
+                ("env_episode", _p), ("driven_path", _p), ("seed_cache", _p)]
 
 
 class SmxSpawns(C.Structure):

@@ -12,45 +12,22 @@
 #define SMX_TWO_PI 6.283185307179586
 #define SMX_HALF_PI 1.5707963267948966
 
-// Device copy of smx_map_tables (same field meaning, device pointers).
-struct MapDev {
-  int32_t n_lanes, n_roads, n_lanepoints, n_shape_pts, n_segments;
-  const int32_t* lane_road;
-  const int32_t* lane_index;
-  const double* lane_width;
-  const double* lane_speed;
-  const double* lane_length;
-  const uint8_t* lane_in_junction;
-  const int32_t* lane_shape_off;
-  const double* shape_x;
-  const double* shape_y;
-  const int32_t* lane_out_off;
-  const int32_t* lane_out_idx;
-  const int32_t* road_lane_off;
-  const int32_t* road_lanes;
-  const uint8_t* road_is_junction;
-  const int32_t* road_out_road;
-  const double* lp_x;
-  const double* lp_y;
-  const double* lp_heading;
-  const double* lp_dirx;
-  const double* lp_diry;
-  const int32_t* lp_lane;
-  const uint8_t* lp_inferred;
-  const int32_t* lp_next_off;
-  const int32_t* lp_next_idx;
-  double lpg_x0, lpg_y0, lpg_cell;
-  int32_t lpg_nx, lpg_ny;
-  const int32_t* lpg_off;
-  const int32_t* lpg_idx;
-  const int32_t* seg_lane;
-  const int32_t* seg_v0;
-  double sg_x0, sg_y0, sg_cell;
-  int32_t sg_nx, sg_ny;
-  const int32_t* sg_off;
-  const int32_t* sg_idx;
-  double default_lane_width;
-};
+// Device copy of smx_map_tables: same fields, device pointers.
+typedef smx_map_tables MapDev;
+
+// Developer build (-DSMX_DEBUG_BOUNDS): every table index is checked; the first violation's site
+// code and value are recorded instead of faulting.
+#ifdef SMX_DEBUG_BOUNDS
+__device__ int smx_dbg_site = 0;
+__device__ long long smx_dbg_value = 0;
+__device__ int smx_dbg_aux[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SMX_BCHK(site, idx, n)                                                  \
+  (((idx) < 0 || (long long)(idx) >= (long long)(n))                            \
+       ? (atomicCAS(&smx_dbg_site, 0, (site)) == 0 ? (smx_dbg_value = (long long)(idx), 0) : 0) \
+       : (idx))
+#else
+#define SMX_BCHK(site, idx, n) (idx)
+#endif
 
 // ---------------------------------------------------------------------------------
 // angle helpers (reference smarts/core/utils/math.py, smarts/core/coordinates.py)

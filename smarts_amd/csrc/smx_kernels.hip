@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,7 @@ struct KernelArgs {
   const double* lidar_rays;
   int envs_per_block;
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
+  int debug_skip;  // developer ablation mask (SMX_DEBUG_SKIP env var), 0 in production
 };
 
 // Pose block shared by the vehicles of the envs of one workgroup (LDS).
@@ -46,7 +48,7 @@ struct __align__(16) SharedPose {
   int lane;          // nearest lane within SMX_POSE_SCAN_RADIUS, -1 none
   int alive;
   int on_road;       // road_with_point(centre) is not None
-  int pad;
+  int corner_mask;   // bit q: road_with_point(bounding-box corner q) is not None
 };
 
 // ---------------------------------------------------------------------------------
@@ -82,7 +84,7 @@ __device__ __forceinline__ double seg_point_dist2(double px, double py, double a
   return ex * ex + ey * ey;
 }
 
-__device__ inline bool boxes_within(double ax, double ay, double ah, double bx, double by, double bh, double len,
+__device__ __noinline__ bool boxes_within(double ax, double ay, double ah, double bx, double by, double bh, double len,
                                     double wid, double leeway) {
   // broad phase: circumscribed circles
   double dx = ax - bx, dy = ay - by;
@@ -168,6 +170,34 @@ __device__ __forceinline__ void zero_outputs(const KernelArgs& a, size_t gid) {
 }
 
 
+__device__ __forceinline__ void store_seeds(const KernelArgs& a, size_t gid, size_t total, const PathSeeds& s) {
+  int32_t* c = a.st.seed_cache;
+  c[0 * total + gid] = s.road;
+  c[1 * total + gid] = s.f.n;
+  c[2 * total + gid] = s.f.n > 0 ? s.f.road[0] : -1;
+  c[3 * total + gid] = s.f.n > 1 ? s.f.road[1] : -1;
+  c[4 * total + gid] = s.n_lanes;
+  c[5 * total + gid] = s.start[0];
+  c[6 * total + gid] = s.start[1];
+  c[7 * total + gid] = s.start[2];
+  c[8 * total + gid] = s.start[3];
+}
+
+__device__ __forceinline__ PathSeeds load_seeds(const KernelArgs& a, size_t gid, size_t total) {
+  const int32_t* c = a.st.seed_cache;
+  PathSeeds s;
+  s.road = c[0 * total + gid];
+  s.f.n = c[1 * total + gid];
+  s.f.road[0] = c[2 * total + gid];
+  s.f.road[1] = c[3 * total + gid];
+  s.n_lanes = c[4 * total + gid];
+  s.start[0] = c[5 * total + gid];
+  s.start[1] = c[6 * total + gid];
+  s.start[2] = c[7 * total + gid];
+  s.start[3] = c[8 * total + gid];
+  return s;
+}
+
 // ---------------------------------------------------------------------------------
 // lane heading at the centre-line point closest to (px, py):
 //   Lane.center_pose_at_point(point).heading  (road_map.py:390-396)
@@ -215,8 +245,8 @@ __device__ inline void position_at_shape_offset(const MapDev& m, int v0, int v1,
   oy = m.shape_y[v1 - 1];
 }
 
-__device__ inline double lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
-  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+__device__ __noinline__ double lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
+  const int v0 = m.lane_shape_off[SMX_BCHK(31, lane, m.n_lanes)], v1 = m.lane_shape_off[lane + 1];
   // offset_along_lane
   double offset;
   {
@@ -284,6 +314,7 @@ struct ObserveCtx {
   double prev_x, prev_y;  // position at the previous observation
   bool first;     // observation produced by a reset
   bool write_reward;
+  int* knots;     // per-thread knot scratch (LDS), stride SMX_BLOCK
 };
 
 __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k, const VehState& s, int& flags) {
@@ -357,7 +388,7 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
 
   // ---- neighbourhood (sensors.py:241-266, smarts.py:1191-1208): every other vehicle of the
   //      instance within `radius` (3-D distance), in slot order, first nb_max kept
-  if (c.sensors & SMX_SENSOR_NEIGHBORS) {
+  if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !(a.debug_skip & 8)) {
     int cnt = 0;
     for (int j = 0; j < k.n_veh; ++j) {
       if (j == k.slot) continue;
@@ -402,21 +433,18 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
   // ---- trip meter construction on a fresh vehicle (TripMeterSensor.__init__, sensors.py:885-898)
   double dist = SF(SMX_S_DIST);
   if (k.first) {
-    PathSeed seed = resolve_path_seed(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
+    PathSeeds seed = compute_path_seeds(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
     flags &= ~SMX_F_TRIP_HAS_WP;
-    if (seed.road >= 0) {
-      int lane = m.road_lanes[m.road_lane_off[seed.road]];
-      int start = closest_lanepoint_filtered(m, px, py, lane, false);
-      if (start >= 0) {
-        BranchState bs;
-        bs.reset();
-        equally_spaced_path(m, seed.f, bs, start, 1, px, py, 1, [&](int, const WaypointOut& w) {
-          SF(SMX_S_TRIP_X) = w.x;
-          SF(SMX_S_TRIP_Y) = w.y;
-          SF(SMX_S_TRIP_H) = w.heading;
-          flags |= SMX_F_TRIP_HAS_WP;
-        });
-      }
+    if (seed.road >= 0 && seed.start[0] >= 0) {
+      BranchState bs;
+      bs.reset();
+      equally_spaced_path(m, seed.f, bs, seed.start[0], 1, px, py, k.knots, SMX_BLOCK, 1,
+                          [&](int, const WaypointOut& w) {
+                            SF(SMX_S_TRIP_X) = w.x;
+                            SF(SMX_S_TRIP_Y) = w.y;
+                            SF(SMX_S_TRIP_H) = w.heading;
+                            flags |= SMX_F_TRIP_HAS_WP;
+                          });
     }
     dist = 0.0;
   }
@@ -428,15 +456,24 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
   {
     const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
     const int lookahead = wp_on ? c.wp_lookahead : 1;
-    PathSeed seed = wp_on ? resolve_path_seed(m, px, py, s.heading, 5.0, true)
-                          : resolve_path_seed(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
+    PathSeeds seed = wp_on ? compute_path_seeds(m, px, py, s.heading, 5.0, true)
+                           : compute_path_seeds(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
+    // the next tick's controller asks for paths at this same pose with the agent's route
+    if (wp_on) {
+      store_seeds(a, gid, total, seed);
+    } else {
+      PathSeeds none;
+      none.road = -2;  // "not cached": the controller computes its own
+      none.f.n = 0;
+      none.n_lanes = 0;
+      none.start[0] = none.start[1] = none.start[2] = none.start[3] = -1;
+      store_seeds(a, gid, total, none);
+    }
     int n_paths = 0;
     const size_t per = (size_t)c.wp_paths * c.wp_len;
-    if (seed.road >= 0) {
-      const int la = m.road_lane_off[seed.road], lb = m.road_lane_off[seed.road + 1];
-      for (int li = la; li < lb; ++li) {
-        int lane = m.road_lanes[li];
-        int start = closest_lanepoint_filtered(m, px, py, lane, false);
+    if (seed.road >= 0 && !(a.debug_skip & 16)) {
+      for (int li = 0; li < seed.n_lanes; ++li) {
+        int start = seed_start(m, seed, li, px, py);
         if (start < 0) continue;
         BranchState bs;
         bs.reset();
@@ -445,7 +482,7 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
           const int max_emit = keep ? c.wp_len : (n_paths == 0 ? 1 : 0);
           const size_t base = gid * per + (size_t)n_paths * c.wp_len;
           const bool is_first_path = (n_paths == 0);
-          int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, max_emit,
+          int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, k.knots, SMX_BLOCK, max_emit,
                                       [&](int i, const WaypointOut& w) {
                                         if (is_first_path && i == 0) {
                                           have_first_wp = true;
@@ -461,7 +498,7 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
                                           o.wp_heading[q] = (float)w.heading;
                                           o.wp_lane_width[q] = (float)w.width;
                                           o.wp_speed_limit[q] = (float)w.speed;
-                                          o.wp_lane_index[q] = (int8_t)m.lane_index[w.lane];
+                                          o.wp_lane_index[q] = (int8_t)m.lane_index[SMX_BCHK(30, w.lane, m.n_lanes)];
                                           o.wp_lane_id[q] = (int16_t)w.lane;
                                         }
                                       });
@@ -552,21 +589,7 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
   // ---- events + done (sensors.py:443-489)
   const bool reached_goal = false;  // EndlessGoal (plan.py:76-84)
   const bool is_off_road = !me.on_road;  // sensors.py:498-500
-  bool is_on_shoulder = false;           // sensors.py:502-509
-  {
-    // Vehicle.bounding_box (vehicle.py:315-332) through rotate_around_point (math.py:436-444)
-    const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
-    const double cys[4] = {0.5, 0.5, -0.5, -0.5};
-    double ch = cos(s.heading), sh = sin(s.heading);
-    for (int q = 0; q < 4 && !is_on_shoulder; ++q) {
-      double qx = px + cxs[q] * SMX_CHASSIS_WIDTH;
-      double qy = py + cys[q] * SMX_CHASSIS_LENGTH;
-      double rx = px + ch * (qx - px) + sh * (qy - py);
-      double ry = py + -sh * (qx - px) + ch * (qy - py);
-      LaneHit h = nearest_lane_scan(m, rx, ry, fmax(5.0, 2.0 * m.default_lane_width));
-      if (!h.on_road) is_on_shoulder = true;
-    }
-  }
+  const bool is_on_shoulder = (me.corner_mask & 15) != 15;  // sensors.py:502-509 (any corner off road)
   const bool reached_max = c.max_episode_steps > 0 && k.steps >= c.max_episode_steps;
   bool is_off_route, is_wrong_way;
   {
@@ -579,7 +602,7 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
     } else {
       is_off_route = false;
       is_wrong_way = false;
-      if (!m.lane_in_junction[nl]) {
+      if (!m.lane_in_junction[nl] && !(a.debug_skip & 64)) {
         double target = lane_heading_at_point(m, nl, px, py);
         is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
       }
@@ -602,9 +625,13 @@ __device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k,
          (is_wrong_way && (dc & SMX_DONE_WRONG_WAY));
 }
 
-// Pose pass: publish this vehicle's pose and its nearest-lane facts to the env-mates.
+// Pose pass: publish this vehicle's pose and its road facts to the env-mates.  One sweep of the
+// segment grid answers the tick's nearest_lane queries at the vehicle centre (ego lane, neighbour
+// lanes, off-route check: all "nearest lane if closer than r") and road_with_point at the centre
+// and at the four bounding-box corners (Vehicle.bounding_box, vehicle.py:315-332, through
+// rotate_around_point, math.py:436-444).
 #define SMX_POSE_SCAN_RADIUS 10.0
-__device__ __forceinline__ void publish_pose(const MapDev& m, SharedPose& p, const VehState& s, bool alive) {
+__device__ __forceinline__ void publish_pose(const MapDev& m, SharedPose& p, const VehState& s, bool alive, int dbg) {
   p.x = s.x;
   p.y = s.y;
   p.heading = wrap_heading(s.heading);
@@ -613,11 +640,25 @@ __device__ __forceinline__ void publish_pose(const MapDev& m, SharedPose& p, con
   p.lane = -1;
   p.lane_dist = SMX_INF;
   p.on_road = 0;
-  if (alive) {
-    LaneHit h = nearest_lane_scan(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width));
+  p.corner_mask = 0;
+  if (alive && !(dbg & 2)) {
+    const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
+    const double cys[4] = {0.5, 0.5, -0.5, -0.5};
+    double cx[4], cy[4];
+    const double ch = cos(s.heading), sh = sin(s.heading);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double qx = s.x + cxs[q] * SMX_CHASSIS_WIDTH;
+      double qy = s.y + cys[q] * SMX_CHASSIS_LENGTH;
+      cx[q] = s.x + ch * (qx - s.x) + sh * (qy - s.y);
+      cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
+    }
+    RoadFacts h = road_facts_scan(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width),
+                                  (dbg & 32) ? 0 : 4, cx, cy);
     p.lane = h.lane;
     p.lane_dist = h.dist;
     p.on_road = h.on_road ? 1 : 0;
+    p.corner_mask = (dbg & 32) ? 15 : h.corner_mask;
   }
 }
 
@@ -628,6 +669,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
   __shared__ SharedPose pose[SMX_BLOCK];
   __shared__ int env_new_done[SMX_BLOCK];
   __shared__ int env_need_reset[SMX_BLOCK];
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  int* knots = knot_scratch + threadIdx.x;
 
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
@@ -678,13 +721,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
       cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
       const int action = a.actions[gid];
       ControlOut co;
-      if (action >= 0) {
+      if (action >= 0 && !(a.debug_skip & 1)) {
         // Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
         double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
         int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
         double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
         double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
-        co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg);
+        PathSeeds seed = load_seeds(a, gid, total);
+        if (seed.road == -2) seed = compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true);
+        co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg, seed, knots, SMX_BLOCK);
       } else {
         // no action this tick: wheel torques do not persist, the steer motor target does
         co.throttle = 0.0;
@@ -702,12 +747,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
       flags = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
     }
     if (valid) ++env_ticks;  // smarts.py:261-262 (every thread of the env keeps the same copy)
-    publish_pose(m, pose[local], s, valid && alive);
+    publish_pose(m, pose[local], s, valid && alive, a.debug_skip);
     __syncthreads();
 
     // ================= C: collisions =================
     bool collided = false;
-    if (valid && alive) {
+    if (valid && alive && !(a.debug_skip & 4)) {
       for (int j = 0; j < n_veh; ++j) {
         if (j == slot) continue;
         const SharedPose& p = env_pose[j];
@@ -736,6 +781,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
         k.prev_y = prev_y;
         k.first = false;
         k.write_reward = true;
+        k.knots = knots;
         done = observe_vehicle(a, k, s, flags);
         // ================= E: teardown (smarts.py:314, 329-363) =================
         if (done) {
@@ -792,7 +838,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
     env_ticks = c.reset_elapsed_steps;
     for (int f = SMX_S_LAT_INT; f < SMX_S_COUNT; ++f) SF(f) = 0.0;
   }
-  publish_pose(m, pose[local], s, do_reset);
+  publish_pose(m, pose[local], s, do_reset, a.debug_skip);
   __syncthreads();
   if (do_reset) {
     ObserveCtx k;
@@ -808,6 +854,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
     k.prev_y = s.y;
     k.first = true;
     k.write_reward = (mode != 0);
+    k.knots = knots;
     observe_vehicle(a, k, s, flags);
     SF(SMX_S_X) = s.x;
     SF(SMX_S_Y) = s.y;
@@ -844,6 +891,7 @@ struct smx_handle_s {
   size_t map_bytes;
   const double* lidar_rays;
   double heading_gain_pos, lateral_gain_pos;
+  int debug_skip;
   bool timing;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2*i] start, [2*i+1] stop
   size_t ev_used;                   // pairs recorded since the last read
@@ -862,6 +910,17 @@ static int fail(smx_handle h, int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; }
+
+#ifdef SMX_DEBUG_BOUNDS
+extern "C" int smx_debug_read(int* site, long long* value) {
+  if (hipMemcpyFromSymbol(site, HIP_SYMBOL(smx_dbg_site), sizeof(int)) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(value, HIP_SYMBOL(smx_dbg_value), sizeof(long long)) != hipSuccess) return -2;
+  int aux[8];
+  if (hipMemcpyFromSymbol(aux, HIP_SYMBOL(smx_dbg_aux), sizeof(aux)) != hipSuccess) return -2;
+  printf("dbg aux: first=%d remaining=%d hops=%d n_next=%d lane=%d next0=%d cur_idx=%d mem_next0=%d\n", aux[0], aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], aux[7]);
+  return 0;
+}
+#endif
 
 extern "C" uint64_t smx_struct_size(int which) {
   switch (which) {
@@ -891,13 +950,17 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->lateral_gain_pos = 3.4;
   h->timing = false;
   h->ev_used = 0;
+  {
+    const char* dbg = getenv("SMX_DEBUG_SKIP");
+    h->debug_skip = dbg ? atoi(dbg) : 0;
+  }
   *out = h;
   const smx_config& c = h->cfg;
   if (c.num_envs <= 0 || c.num_vehicles <= 0 || c.num_vehicles > SMX_BLOCK)
     return fail(h, SMX_ERR_INVALID, "num_envs must be > 0 and 0 < num_vehicles <= 64");
   if (!(c.dt > 0.0)) return fail(h, SMX_ERR_INVALID, "dt must be > 0");
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
-      (c.wp_lookahead < 1 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
+      (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (c.nb_max < 1 || c.nb_max > 127))
     return fail(h, SMX_ERR_INVALID, "neighbours: need 1 <= nb_max <= 127");
@@ -927,12 +990,26 @@ struct BlobWriter {
 
 extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   if (!h || !t) return SMX_ERR_INVALID;
-  if (t->n_lanes <= 0 || t->n_roads <= 0 || t->n_lanepoints <= 0 || t->n_segments <= 0)
-    return fail(h, SMX_ERR_INVALID, "empty map tables");
+  if (t->n_lanes <= 0 || t->n_roads <= 0 || t->n_lanepoints <= 0) return fail(h, SMX_ERR_INVALID, "empty map tables");
   if (t->n_lanes > 32767) return fail(h, SMX_ERR_INVALID, "lane ids are reported as int16: at most 32767 lanes");
   SMX_HIP(hipSetDevice(h->device));
   BlobWriter w;
-  const size_t nl = t->n_lanes, nr = t->n_roads, np_ = t->n_lanepoints, ns = t->n_segments, nv = t->n_shape_pts;
+  const size_t nl = t->n_lanes, nr = t->n_roads, np_ = t->n_lanepoints, nv = t->n_shape_pts;
+  const size_t lpg_cells = (size_t)t->lpg_nx * t->lpg_ny, sg_cells = (size_t)t->sg_nx * t->sg_ny;
+  // every record index stored in the tables is range-checked here, once, so that the kernels can
+  // follow them without bounds tests
+  for (size_t i = 0; i < np_; ++i) {
+    const smx_lp_rec& r = t->lp_rec[i];
+    if (r.lane < 0 || r.lane >= t->n_lanes || r.next0 >= t->n_lanepoints || r.knot_next >= t->n_lanepoints ||
+        (r.n_next > 0 && (r.next_off < 0 || r.next_off + r.n_next > t->n_succ || r.next0 < 0 || r.knot_next < 0)))
+      return fail(h, SMX_ERR_INVALID, "lanepoint record out of range");
+  }
+  for (int i = 0; i < t->n_succ; ++i) {
+    const smx_succ_rec& r = t->succ_rec[i];
+    if (r.idx < 0 || r.idx >= t->n_lanepoints || r.knot < 0 || r.knot >= t->n_lanepoints || r.lane < 0 ||
+        r.lane >= t->n_lanes || r.hops < 1)
+      return fail(h, SMX_ERR_INVALID, "successor record out of range");
+  }
 #define ADD(field, count, type) size_t off_##field = w.add(t->field, (size_t)(count) * sizeof(type))
   ADD(lane_road, nl, int32_t);
   ADD(lane_index, nl, int32_t);
@@ -949,23 +1026,12 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   ADD(road_lanes, t->road_lane_off[nr], int32_t);
   ADD(road_is_junction, nr, uint8_t);
   ADD(road_out_road, nr, int32_t);
-  ADD(lp_x, np_, double);
-  ADD(lp_y, np_, double);
-  ADD(lp_heading, np_, double);
-  ADD(lp_dirx, np_, double);
-  ADD(lp_diry, np_, double);
-  ADD(lp_lane, np_, int32_t);
-  ADD(lp_inferred, np_, uint8_t);
-  ADD(lp_next_off, np_ + 1, int32_t);
-  ADD(lp_next_idx, t->lp_next_off[np_], int32_t);
-  const size_t lpg_cells = (size_t)t->lpg_nx * t->lpg_ny;
+  ADD(lp_rec, np_, smx_lp_rec);
+  ADD(succ_rec, t->n_succ, smx_succ_rec);
   ADD(lpg_off, lpg_cells + 1, int32_t);
-  ADD(lpg_idx, t->lpg_off[lpg_cells], int32_t);
-  ADD(seg_lane, ns, int32_t);
-  ADD(seg_v0, ns, int32_t);
-  const size_t sg_cells = (size_t)t->sg_nx * t->sg_ny;
+  ADD(lpg_pts, t->lpg_off[lpg_cells], smx_pt_rec);
   ADD(sg_off, sg_cells + 1, int32_t);
-  ADD(sg_idx, t->sg_off[sg_cells], int32_t);
+  ADD(sg_rec, t->sg_off[sg_cells], smx_seg_rec);
 #undef ADD
   if (h->map_blob) {
     (void)hipFree(h->map_blob);
@@ -976,11 +1042,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   h->map_bytes = w.host.size();
   char* base = (char*)h->map_blob;
   MapDev& m = h->map;
-  m.n_lanes = t->n_lanes;
-  m.n_roads = t->n_roads;
-  m.n_lanepoints = t->n_lanepoints;
-  m.n_shape_pts = t->n_shape_pts;
-  m.n_segments = t->n_segments;
+  m = *t;  // scalars; every pointer is re-pointed into the device blob below
 #define PTR(field, type) m.field = (const type*)(base + off_##field)
   PTR(lane_road, int32_t);
   PTR(lane_index, int32_t);
@@ -997,33 +1059,13 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   PTR(road_lanes, int32_t);
   PTR(road_is_junction, uint8_t);
   PTR(road_out_road, int32_t);
-  PTR(lp_x, double);
-  PTR(lp_y, double);
-  PTR(lp_heading, double);
-  PTR(lp_dirx, double);
-  PTR(lp_diry, double);
-  PTR(lp_lane, int32_t);
-  PTR(lp_inferred, uint8_t);
-  PTR(lp_next_off, int32_t);
-  PTR(lp_next_idx, int32_t);
+  PTR(lp_rec, smx_lp_rec);
+  PTR(succ_rec, smx_succ_rec);
   PTR(lpg_off, int32_t);
-  PTR(lpg_idx, int32_t);
-  PTR(seg_lane, int32_t);
-  PTR(seg_v0, int32_t);
+  PTR(lpg_pts, smx_pt_rec);
   PTR(sg_off, int32_t);
-  PTR(sg_idx, int32_t);
+  PTR(sg_rec, smx_seg_rec);
 #undef PTR
-  m.lpg_x0 = t->lpg_x0;
-  m.lpg_y0 = t->lpg_y0;
-  m.lpg_cell = t->lpg_cell;
-  m.lpg_nx = t->lpg_nx;
-  m.lpg_ny = t->lpg_ny;
-  m.sg_x0 = t->sg_x0;
-  m.sg_y0 = t->sg_y0;
-  m.sg_cell = t->sg_cell;
-  m.sg_nx = t->sg_nx;
-  m.sg_ny = t->sg_ny;
-  m.default_lane_width = t->default_lane_width;
   h->map_loaded = true;
   return SMX_OK;
 }
@@ -1037,7 +1079,8 @@ extern "C" int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t 
 
 static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp, const smx_outputs* o) {
   if (!st || !sp || !o) return fail(h, SMX_ERR_INVALID, "null state / spawns / outputs");
-  if (!st->f64 || !st->flags || !st->steps || !st->env_ticks || !st->env_done_count || !st->env_episode)
+  if (!st->f64 || !st->flags || !st->steps || !st->env_ticks || !st->env_done_count || !st->env_episode ||
+      !st->seed_cache)
     return fail(h, SMX_ERR_INVALID, "null state buffer");
   if (!sp->pose || sp->episodes < 1) return fail(h, SMX_ERR_INVALID, "spawn table is empty");
   if (!o->ego_pos || !o->ego_f32 || !o->ego_lane || !o->events || !o->reward || !o->dist || !o->done || !o->active ||
@@ -1075,6 +1118,7 @@ static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* 
   a.envs_per_block = SMX_BLOCK / h->cfg.num_vehicles;
   a.heading_gain_pos = h->heading_gain_pos;
   a.lateral_gain_pos = h->lateral_gain_pos;
+  a.debug_skip = h->debug_skip;
   const int blocks = (h->cfg.num_envs + a.envs_per_block - 1) / a.envs_per_block;
   const bool timed = h->timing && mode == 0 && h->ev_used < 65536;
   if (timed) {

@@ -4,30 +4,45 @@
 //   LanePoints.closest_lanepoints / closest_linked_*      lanepoints.py:526-644
 //   LanePoints.paths_starting_at_lanepoint                lanepoints.py:646-692
 //   SumoRoadNetwork.waypoint_paths / _equally_spaced_path sumo_road_network.py:815-882, 1312-1437
-// over flat tables (smx_map_tables) with uniform grids instead of KD-/R-trees.
+// over packed tables (smx_map_tables) with uniform grids instead of KD-/R-trees.
+//
+// Memory behaviour is the design driver: one thread's tick used to be ~5000 *dependent*
+// cache misses.  Here a lanepoint is one 64-byte record, grid cells hold their members by
+// value, a path walk visits only the shape points it passes (knot skip-links), the five
+// nearest-lane queries of a tick share one cell sweep, and the lanepoint searches of a tick
+// are two sweeps whose results are reused by the next tick's controller.
 #pragma once
 #include "smx_device.h"
 
 #define SMX_INF 1.0e300
 
+__device__ __forceinline__ smx_lp_rec load_lp(const MapDev& m, int i, int site = 1) {
+  return m.lp_rec[SMX_BCHK(site, i, m.n_lanepoints)];
+}
+
 // ---------------------------------------------------------------------------------
-// nearest lane(s)
+// nearest lane(s): centre + 4 corners of a vehicle in one sweep
 // ---------------------------------------------------------------------------------
-struct LaneHit {
-  int lane;      // argmin-distance lane (ties: lowest table index), -1 if none within radius
-  double dist;   // its centre-line distance
-  bool on_road;  // road_with_point(): some lane with dist < 0.5*width + 0.1 within road radius
+struct RoadFacts {
+  int lane;         // nearest lane to the centre within `radius` (ties: lowest table index), -1 none
+  double dist;      // its centre-line distance
+  bool on_road;     // road_with_point(centre) is not None
+  int corner_mask;  // bit q: road_with_point(corner q) is not None
 };
 
-// All lanes whose centre polyline is closer than `radius` to (px, py); the nearest one is
-// what RoadMap.nearest_lane returns (road_map.py:91-96).  The segment grid only prunes: a
-// lane is within `radius` iff one of its segments is, and that segment's bounding box then
-// meets the query square, so it is listed in a visited cell.
-__device__ inline LaneHit nearest_lane_scan(const MapDev& m, double px, double py, double radius) {
-  LaneHit hit;
-  hit.lane = -1;
-  hit.dist = SMX_INF;
-  hit.on_road = false;
+// All lanes whose centre polyline is closer than `radius` to the centre; the nearest one is what
+// RoadMap.nearest_lane returns (road_map.py:91-96).  The segment grid only prunes: a lane is
+// within reach iff one of its segments is, and that segment's bounding box then meets the query
+// square, so it is listed in a visited cell.  Corners are at most half a vehicle diagonal from
+// the centre and only ask for segments closer than half a lane width, so the same sweep
+// answers them (n_corners = 0 skips them).
+__device__ __noinline__ RoadFacts road_facts_scan(const MapDev& m, double px, double py, double radius, int n_corners,
+                                            const double* cx, const double* cy) {
+  RoadFacts out;
+  out.lane = -1;
+  out.dist = SMX_INF;
+  out.on_road = false;
+  out.corner_mask = 0;
   const double road_radius = fmax(5.0, 2.0 * m.default_lane_width);  // sumo_road_network.py:705
   int cx0 = (int)floor((px - radius - m.sg_x0) / m.sg_cell);
   int cx1 = (int)floor((px + radius - m.sg_x0) / m.sg_cell);
@@ -37,43 +52,79 @@ __device__ inline LaneHit nearest_lane_scan(const MapDev& m, double px, double p
   cy0 = max(cy0, 0);
   cx1 = min(cx1, m.sg_nx - 1);
   cy1 = min(cy1, m.sg_ny - 1);
-  for (int cy = cy0; cy <= cy1; ++cy) {
-    for (int cx = cx0; cx <= cx1; ++cx) {
-      int c = cy * m.sg_nx + cx;
-      int a = m.sg_off[c], b = m.sg_off[c + 1];
-      for (int k = a; k < b; ++k) {
-        int s = m.sg_idx[k];
-        int v = m.seg_v0[s];
-        int lane = m.seg_lane[s];
-        double d = dist_point_segment(px, py, m.shape_x[v], m.shape_y[v], m.shape_x[v + 1], m.shape_y[v + 1]);
-        if (d < radius) {
-          if (d < hit.dist || (d == hit.dist && lane < hit.lane)) {
-            hit.dist = d;
-            hit.lane = lane;
+  for (int gy = cy0; gy <= cy1; ++gy) {
+    const int row = gy * m.sg_nx;
+    // cells of one grid row are contiguous in the member array
+    const int a = m.sg_off[SMX_BCHK(2, row + cx0, m.sg_nx * m.sg_ny + 1)], b = m.sg_off[SMX_BCHK(3, row + cx1 + 1, m.sg_nx * m.sg_ny + 1)];
+    for (int k = a; k < b; ++k) {
+      const smx_seg_rec s = m.sg_rec[SMX_BCHK(4, k, m.sg_off[m.sg_nx * m.sg_ny])];
+      // distance_point_to_line(point, p1, p2) (math.py:393-411), shared segment length
+      const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
+      const double d = sqrt(ex * ex + ey * ey);
+      const double dd = d * d;
+      const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
+#pragma unroll
+      for (int q = -1; q < 4; ++q) {
+        if (q >= n_corners) break;
+        const double qx = q < 0 ? px : cx[q], qy = q < 0 ? py : cy[q];
+        const double u = ((qx - s.x1) * sx) + ((qy - s.y1) * sy);
+        double offset;
+        if (d == 0.0 || u < 0.0 || u > dd) {
+          offset = (u < 0.0) ? 0.0 : d;
+        } else {
+          offset = u / d;
+        }
+        double dist;
+        if (offset == 0.0) {
+          const double fx = qx - s.x1, fy = qy - s.y1;
+          dist = sqrt(fx * fx + fy * fy);
+        } else {
+          const double uu = offset / d;
+          const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
+          const double fx = qx - ix, fy = qy - iy;
+          dist = sqrt(fx * fx + fy * fy);
+        }
+        if (q < 0) {
+          if (dist < radius) {
+            if (dist < out.dist || (dist == out.dist && s.lane < out.lane)) {
+              out.dist = dist;
+              out.lane = s.lane;
+            }
+            if (dist < road_radius && dist < s.thr) out.on_road = true;
           }
-          if (d < road_radius && d < 0.5 * m.lane_width[lane] + 1e-1) hit.on_road = true;
+        } else {
+          if (dist < road_radius && dist < s.thr) out.corner_mask |= (1 << q);
         }
       }
     }
   }
-  return hit;
+  return out;
 }
 
 // ---------------------------------------------------------------------------------
 // lanepoint nearest-neighbour queries on the uniform grid
 // ---------------------------------------------------------------------------------
-// Visit every lanepoint in ring `r` (Chebyshev) around cell (cx, cy).
+// Visit every lanepoint of Chebyshev ring `r` around cell (cx, cy).
 template <class F>
 __device__ __forceinline__ void lp_ring_visit(const MapDev& m, int cx, int cy, int r, F&& f) {
-  int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+  const int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
   for (int y = max(y0, 0); y <= min(y1, m.lpg_ny - 1); ++y) {
-    bool edge_row = (y == y0) || (y == y1);
-    int step = edge_row ? 1 : max(2 * r, 1);
-    for (int x = x0; x <= x1; x += step) {
-      if (x < 0 || x >= m.lpg_nx) continue;
-      int c = y * m.lpg_nx + x;
-      int a = m.lpg_off[c], b = m.lpg_off[c + 1];
-      for (int k = a; k < b; ++k) f(m.lpg_idx[k]);
+    const int row = y * m.lpg_nx;
+    if (y == y0 || y == y1) {
+      // full edge row: its cells are contiguous
+      const int xa = max(x0, 0), xb = min(x1, m.lpg_nx - 1);
+      if (xa > xb) continue;
+      const int a = m.lpg_off[SMX_BCHK(5, row + xa, m.lpg_nx * m.lpg_ny + 1)], b = m.lpg_off[SMX_BCHK(6, row + xb + 1, m.lpg_nx * m.lpg_ny + 1)];
+      for (int k = a; k < b; ++k) f(m.lpg_pts[SMX_BCHK(7, k, m.n_lanepoints)]);
+    } else {
+      if (x0 >= 0 && x0 < m.lpg_nx) {
+        const int a = m.lpg_off[SMX_BCHK(8, row + x0, m.lpg_nx * m.lpg_ny + 1)], b = m.lpg_off[row + x0 + 1];
+        for (int k = a; k < b; ++k) f(m.lpg_pts[SMX_BCHK(9, k, m.n_lanepoints)]);
+      }
+      if (x1 != x0 && x1 >= 0 && x1 < m.lpg_nx) {
+        const int a = m.lpg_off[SMX_BCHK(10, row + x1, m.lpg_nx * m.lpg_ny + 1)], b = m.lpg_off[row + x1 + 1];
+        for (int k = a; k < b; ++k) f(m.lpg_pts[SMX_BCHK(11, k, m.n_lanepoints)]);
+      }
     }
   }
 }
@@ -91,107 +142,126 @@ __device__ __forceinline__ bool ring_covers(const MapDev& m, int r, double d2) {
   return d2 <= reach * reach;
 }
 
-// closest_lanepoints([pose], within_radius, maximum_count=10)[0] (lanepoints.py:526-623):
-// the 10 nearest lanepoints, those beyond within_radius dropped (the nearest always kept),
-// winner = min of dist^2 + |heading difference|.  Ties resolve to the nearer point, then to the
-// lower table index.  within_radius < 0 means None.
-__device__ inline int closest_lanepoint(const MapDev& m, double px, double py, double heading,
-                                        double within_radius) {
+// The 10 nearest lanepoints (maximum_count = 10, lanepoints.py:592-623), sorted by
+// (distance^2, table index).
+struct Top10 {
+  double d2[10];
+  int idx[10];
+};
+
+__device__ __noinline__ void nearest10(const MapDev& m, double px, double py, Top10& t) {
   const int K = 10;
-  double bd[K];
-  int bi[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    bd[i] = SMX_INF;
-    bi[i] = -1;
+    t.d2[i] = SMX_INF;
+    t.idx[i] = -1;
   }
-  int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
-  int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
-  int keff = min(K, m.n_lanepoints);
-  int rmax = lp_max_ring(m, cx, cy);
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int keff = min(K, m.n_lanepoints);
+  const int rmax = lp_max_ring(m, cx, cy);
   for (int r = 0; r <= rmax; ++r) {
-    lp_ring_visit(m, cx, cy, r, [&](int i) {
-      double dx = m.lp_x[i] - px, dy = m.lp_y[i] - py;
+    lp_ring_visit(m, cx, cy, r, [&](const smx_pt_rec& p) {
+      double dx = p.x - px, dy = p.y - py;
       double d2 = dx * dx + dy * dy;
-      if (d2 < bd[K - 1] || (d2 == bd[K - 1] && i < bi[K - 1])) {
-        // insert into the sorted top-K (registers; fully unrolled bubble)
+      if (d2 < t.d2[K - 1] || (d2 == t.d2[K - 1] && p.idx < t.idx[K - 1])) {
         double cd = d2;
-        int ci = i;
+        int ci = p.idx;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          bool lt = (cd < bd[k]) || (cd == bd[k] && ci < bi[k]);
-          double td = lt ? bd[k] : cd;
-          int ti = lt ? bi[k] : ci;
-          bd[k] = lt ? cd : bd[k];
-          bi[k] = lt ? ci : bi[k];
+          bool lt = (cd < t.d2[k]) || (cd == t.d2[k] && ci < t.idx[k]);
+          double td = lt ? t.d2[k] : cd;
+          int ti = lt ? t.idx[k] : ci;
+          t.d2[k] = lt ? cd : t.d2[k];
+          t.idx[k] = lt ? ci : t.idx[k];
           cd = td;
           ci = ti;
         }
       }
     });
-    if (bi[keff - 1] >= 0 && ring_covers(m, r, bd[keff - 1])) break;
+    // keff is 10 except on maps with fewer lanepoints
+    bool full = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k == keff - 1) full = t.idx[k] >= 0 && ring_covers(m, r, t.d2[k]);
+    if (full) break;
   }
-  double r2 = within_radius * within_radius;
+}
+
+// closest_lanepoints([pose], within_radius)[0] from the 10 nearest (lanepoints.py:526-590):
+// those beyond within_radius dropped (the nearest always kept), winner = min of
+// dist^2 + |heading difference| (first minimum in distance order).  within_radius < 0 = None.
+__device__ inline int pick_closest(const MapDev& m, const Top10& t, double heading, double within_radius) {
+  const double r2 = within_radius * within_radius;
   int best = -1;
   double best_score = SMX_INF;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (bi[k] < 0) continue;
-    if (within_radius >= 0.0 && k > 0 && !(bd[k] <= r2)) continue;
-    double score = bd[k] + fabs(heading_relative_to(heading, m.lp_heading[bi[k]]));
+  for (int k = 0; k < 10; ++k) {
+    if (t.idx[k] < 0) continue;
+    if (within_radius >= 0.0 && k > 0 && !(t.d2[k] <= r2)) continue;
+    double score = t.d2[k] + fabs(heading_relative_to(heading, m.lp_rec[SMX_BCHK(12, t.idx[k], m.n_lanepoints)].heading));
     if (score < best_score) {
       best_score = score;
-      best = bi[k];
+      best = t.idx[k];
     }
   }
   return best;
 }
 
-// closest_linked_lanepoint_on_lane_to_point (lanepoints.py:629-636) when by_road == false,
-// closest_linked_lanepoint_on_road (lanepoints.py:638-644) when by_road == true.
-__device__ inline int closest_lanepoint_filtered(const MapDev& m, double px, double py, int key, bool by_road,
-                                                 double* out_d2 = nullptr) {
-  int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
-  int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
-  int rmax = lp_max_ring(m, cx, cy);
-  double bd = SMX_INF;
-  int bi = -1;
+// closest_linked_lanepoint_on_lane_to_point (lanepoints.py:629-636) for up to 4 lanes at once
+// (by_road == false), or closest_linked_lanepoint_on_road (:638-644) for up to 4 roads.
+__device__ __noinline__ void closest_filtered4(const MapDev& m, double px, double py, const int* keys, int nkeys,
+                                         bool by_road, int* out_idx, double* out_d2) {
+  double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
+  int bi[4] = {-1, -1, -1, -1};
+  const int k0 = keys[0], k1 = nkeys > 1 ? keys[1] : -9, k2 = nkeys > 2 ? keys[2] : -9, k3 = nkeys > 3 ? keys[3] : -9;
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int rmax = lp_max_ring(m, cx, cy);
   for (int r = 0; r <= rmax; ++r) {
-    lp_ring_visit(m, cx, cy, r, [&](int i) {
-      int lane = m.lp_lane[i];
-      int k = by_road ? m.lane_road[lane] : lane;
-      if (k != key) return;
-      double dx = m.lp_x[i] - px, dy = m.lp_y[i] - py;
+    lp_ring_visit(m, cx, cy, r, [&](const smx_pt_rec& p) {
+      const int key = by_road ? m.lane_road[SMX_BCHK(13, p.lane, m.n_lanes)] : p.lane;
+      double dx = p.x - px, dy = p.y - py;
       double d2 = dx * dx + dy * dy;
-      if (d2 < bd || (d2 == bd && i < bi)) {
-        bd = d2;
-        bi = i;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+        if (key == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+          bd[q] = d2;
+          bi[q] = p.idx;
+        }
       }
     });
-    if (bi >= 0 && ring_covers(m, r, bd)) break;
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nkeys) all = all && bi[q] >= 0 && ring_covers(m, r, bd[q]);
+    if (all) break;
   }
-  if (out_d2) *out_d2 = bd;
-  return bi;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    out_idx[q] = bi[q];
+    if (out_d2) out_d2[q] = bd[q];
+  }
 }
 
 // ---------------------------------------------------------------------------------
-// lanepoint paths (lanepoints.py:646-692) and equally spaced waypoints
-// (sumo_road_network.py:1312-1437)
+// lanepoint paths (lanepoints.py:646-692)
 // ---------------------------------------------------------------------------------
 // Route filter: the road ids of _resolve_in_junction (at most the junction road and the
 // road it leads to), or none.
 struct RouteFilter {
-  int n;       // 0 = no filter
+  int n;  // 0 = no filter
   int road[2];
   __device__ __forceinline__ bool has(int r) const { return (n > 0 && road[0] == r) || (n > 1 && road[1] == r); }
   __device__ __forceinline__ int last() const { return road[n - 1]; }
 };
 
-// lanepoints.py:666-683: may the walk continue onto lanepoint `nx`?
-__device__ __forceinline__ bool next_allowed(const MapDev& m, const RouteFilter& f, int nx) {
+// lanepoints.py:666-683: may a path continue onto a lanepoint of `lane`?  (A pure function of
+// the lane, so a walk is checked where the lane changes, not per hop.)
+__device__ __forceinline__ bool lane_allowed(const MapDev& m, const RouteFilter& f, int lane) {
   if (f.n == 0) return true;
-  int lane = m.lp_lane[nx];
-  int road = m.lane_road[lane];
+  const int road = m.lane_road[SMX_BCHK(14, lane, m.n_lanes)];
   if (!f.has(road)) return false;
   if (road != f.last()) {
     bool any = false;
@@ -229,37 +299,128 @@ struct BranchState {
   }
 };
 
-// One hop of the walk: returns the next lanepoint or -1 when the path cannot grow.
-__device__ __forceinline__ int walk_next(const MapDev& m, const RouteFilter& f, BranchState& bs, int& level, int lp) {
-  int a = m.lp_next_off[lp], b = m.lp_next_off[lp + 1];
-  int n = b - a;
-  if (n == 0) return -1;
-  if (n == 1) {
-    int nx = m.lp_next_idx[a];
-    return next_allowed(m, f, nx) ? nx : -1;
-  }
-  int allowed = 0;
-  for (int k = a; k < b; ++k) allowed += next_allowed(m, f, m.lp_next_idx[k]) ? 1 : 0;
-  if (allowed == 0) return -1;
-  int want = 0;
-  if (allowed > 1) {
-    if (level < bs.nb) {
-      want = bs.get_choice(level);
-    } else if (level < 16) {
-      bs.set(level, 0, min(allowed, 15));
-      bs.nb = level + 1;
-    }
-    ++level;
-  }
-  int seen = 0;
-  for (int k = a; k < b; ++k) {
-    int nx = m.lp_next_idx[k];
-    if (!next_allowed(m, f, nx)) continue;
-    if (seen == want) return nx;
-    ++seen;
-  }
-  return -1;
+// j-th successor (j >= 0) down a chain of interpolated lanepoints starting at `first`.
+__device__ __forceinline__ int chain_at(const MapDev& m, int first, int j, bool consecutive) {
+  if (consecutive) return first + j;
+  int cur = first;
+  for (int k = 0; k < j; ++k) cur = m.lp_rec[cur].next0;
+  return cur;
 }
+
+// Knot walker: enumerates, for one lanepoint path, the lanepoints that become interpolation
+// knots — every non-inferred lanepoint after the start, and the last lanepoint — without
+// touching the interpolated points in between.
+struct KnotWalk {
+  int remaining;  // hops still allowed
+  int n;          // lanepoints on the path so far (start included)
+  int level;      // branching level (BranchState index)
+  smx_lp_rec cur; // record of the lanepoint the walk stands on
+  bool start;     // still on the start point (its own lane has not been checked by the filter)
+  int cur_idx;    // index of `cur`
+
+  __device__ __forceinline__ void begin(const MapDev& m, int start_lp, int lookahead) {
+    remaining = lookahead;
+    n = 1;
+    level = 0;
+    cur = load_lp(m, start_lp, 40);
+    cur_idx = start_lp;
+    start = true;
+  }
+
+  // Advance to the next knot.  Returns its lanepoint index (its record is left in `rec`),
+  // or -1 when the path has ended.  `last` tells whether it is the path's last lanepoint.
+  __device__ inline int next(const MapDev& m, const RouteFilter& f, BranchState& bs, smx_lp_rec& rec, bool& last) {
+    if (remaining <= 0 || cur.n_next == 0) return -1;
+    int first, knot, hops, first_lane;
+    if (cur.n_next == 1) {
+      first = cur.next0;
+      knot = cur.knot_next;
+      hops = cur.knot_hops;
+      first_lane = -1;  // same lane as `cur` when interpolated, else the knot's own lane
+    } else {
+      int allowed = 0;
+      const int a = cur.next_off, b = a + cur.n_next;
+      for (int k = a; k < b; ++k) allowed += lane_allowed(m, f, m.succ_rec[SMX_BCHK(15, k, m.n_succ)].lane) ? 1 : 0;
+      if (allowed == 0) return -1;
+      int want = 0;
+      if (allowed > 1) {
+        if (level < bs.nb) {
+          want = bs.get_choice(level);
+        } else if (level < 16) {
+          bs.set(level, 0, min(allowed, 15));
+          bs.nb = level + 1;
+        }
+        ++level;
+      }
+      int seen = 0;
+      first = -1;
+      knot = -1;
+      hops = 0;
+      first_lane = -1;
+      for (int k = a; k < b; ++k) {
+        const smx_succ_rec sr = m.succ_rec[k];
+        if (!lane_allowed(m, f, sr.lane)) continue;
+        if (seen == want) {
+          first = sr.idx;
+          knot = sr.knot;
+          hops = sr.hops;
+          first_lane = sr.lane;
+          break;
+        }
+        ++seen;
+      }
+      if (first < 0) return -1;
+    }
+    const bool consecutive = (cur.flags & 1) != 0;
+    if (hops > 1 && cur.n_next == 1 && start && !lane_allowed(m, f, cur.lane)) return -1;
+    start = false;
+    if (hops <= remaining) {
+      rec = load_lp(m, knot, 41);
+      // arriving on the knot is a hop onto its lane
+      const bool ok = (hops > 1 || cur.n_next == 1 || first_lane == rec.lane) ? lane_allowed(m, f, rec.lane) : true;
+      if (ok) {
+        remaining -= hops;
+        n += hops;
+        cur = rec;
+        cur_idx = knot;
+        last = (remaining == 0) || (rec.n_next == 0);
+        if (!last) {
+          // the path also ends here if no successor can be taken; found out by the next call
+        }
+        return knot;
+      }
+      if (hops == 1) return -1;
+      // the knot's lane is closed: the path stops on the interpolated point before it
+      const int fin = chain_at(m, first, hops - 2, consecutive);
+      rec = load_lp(m, fin, 42);
+      n += hops - 1;
+      remaining = 0;
+      cur = rec;
+      last = true;
+      return fin;
+    }
+    // the path stops inside the interpolated run
+    const int fin = chain_at(m, first, remaining - 1, consecutive);
+#ifdef SMX_DEBUG_BOUNDS
+    if (fin < 0 || fin >= m.n_lanepoints) {
+      smx_dbg_aux[0] = first;
+      smx_dbg_aux[1] = remaining;
+      smx_dbg_aux[2] = hops;
+      smx_dbg_aux[3] = cur.n_next;
+      smx_dbg_aux[4] = cur.lane;
+      smx_dbg_aux[5] = cur.next0;
+      smx_dbg_aux[6] = cur_idx;
+      smx_dbg_aux[7] = ((const volatile smx_lp_rec*)m.lp_rec)[cur_idx].next0;
+    }
+#endif
+    rec = load_lp(m, fin, 43);
+    n += remaining;
+    remaining = 0;
+    cur = rec;
+    last = true;
+    return fin;
+  }
+};
 
 // Running heading unwrap (math.py:537-550), one element at a time.
 struct Unwrap {
@@ -286,122 +447,115 @@ struct WaypointOut {
   int lane;
 };
 
-// Equally spaced waypoints of ONE lanepoint path (sumo_road_network.py:1312-1437), streamed.
+#define SMX_MAX_KNOTS 36  // lookahead <= 34: start + at most one knot per hop + the last point
+
+// Equally spaced waypoints of ONE lanepoint path (sumo_road_network.py:1312-1437).
 //   start     first lanepoint of the path
 //   lookahead number of hops requested
 //   bs        branch choices selecting this path (updated with newly met branchings)
 //   (px, py)  the query point (vehicle position)
+//   knots     per-thread scratch for the path's knot indices ([SMX_MAX_KNOTS], stride `kstride`)
 //   max_emit  emit(i, wp) is called for i < min(max_emit, #waypoints)
 // Returns the number of waypoints of the path (= number of lanepoints on it).
 //
 // The reference keeps, as interpolation knots, the first lanepoint (moved to the projection of
 // the query point on its heading line), every non-inferred lanepoint strictly inside the path,
-// and the last lanepoint.  Pass 1 walks the path for its knot arclength D; pass 2 walks it again
-// and emits the waypoints t_i = i * D / (n - 1) by np.interp's rule (knot j = last knot with
-// cum[j] <= t; exact knot value when t == cum[j]) while lane_id / lane_index follow the
-// "last knot strictly passed" rule of :1404-1417.
+// and the last lanepoint.  Pass 1 walks the knots (dependent loads, one record per knot) for the
+// path length n and the knot arclength D, remembering the knot indices; pass 2 re-reads those
+// records (independent loads) and emits the waypoints t_i = i * D / (n - 1) by np.interp's rule
+// (knot j = last knot with cum[j] <= t; exact knot value when t == cum[j]) while lane_id /
+// lane_index follow the "last knot strictly passed" rule of :1404-1417.
 template <class Emit>
 __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f, BranchState& bs, int start,
-                                          int lookahead, double px, double py, int max_emit, Emit&& emit) {
-  // ---- knot 0
-  const double l0x = m.lp_x[start], l0y = m.lp_y[start];
-  const double hx = m.lp_dirx[start], hy = m.lp_diry[start];
-  const double proj = (px - l0x) * hx + (py - l0y) * hy;
-  const double k0x = l0x + proj * hx, k0y = l0y + proj * hy;
+                                          int lookahead, double px, double py, int* knots, int kstride,
+                                          int max_emit, Emit&& emit) {
+  KnotWalk w;
+  w.begin(m, start, lookahead);
+  const smx_lp_rec r0 = w.cur;
+  // ---- knot 0: projection of the query point on the first lanepoint's heading line
+  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+  const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
 
-  // ---- pass 1: path length in lanepoints and knot arclength
-  int n = 1;
+  // ---- pass 1
+  int nk = 0;
   double D = 0.0;
   {
-    int level = 0;
-    int lp = start;
     double lastx = k0x, lasty = k0y;
-    int cur = start;
-    bool cur_is_knot = true;
-    for (int hop = 0; hop < lookahead; ++hop) {
-      int nx = walk_next(m, f, bs, level, lp);
-      if (nx < 0) break;
-      lp = nx;
-      ++n;
-      cur = nx;
-      cur_is_knot = !m.lp_inferred[nx];
-      if (cur_is_knot) {
-        double qx = m.lp_x[nx], qy = m.lp_y[nx];
-        double ex = qx - lastx, ey = qy - lasty;
-        D += sqrt(ex * ex + ey * ey);
-        lastx = qx;
-        lasty = qy;
-      }
-    }
-    if (!cur_is_knot) {
-      double ex = m.lp_x[cur] - lastx, ey = m.lp_y[cur] - lasty;
+    smx_lp_rec rec;
+    bool last = false;
+    for (;;) {
+      int idx = w.next(m, f, bs, rec, last);
+      if (idx < 0) break;
+      if (nk < SMX_MAX_KNOTS) knots[nk * kstride] = idx;
+      (void)SMX_BCHK(16, nk, SMX_MAX_KNOTS);
+      ++nk;
+      double ex = rec.x - lastx, ey = rec.y - lasty;
       D += sqrt(ex * ex + ey * ey);
+      lastx = rec.x;
+      lasty = rec.y;
     }
   }
-  const int lane0 = m.lp_lane[start];
+  const int n = w.n;
+  const int lane0 = r0.lane;
   if (n == 1) {
     // :1379-1390 (a one-point path): the lanepoint itself, not the projection
     if (max_emit > 0) {
-      WaypointOut w;
-      w.x = l0x;
-      w.y = l0y;
-      w.heading = m.lp_heading[start];
-      w.width = m.lane_width[lane0];
-      w.speed = m.lane_speed[lane0];
-      w.lane = lane0;
-      emit(0, w);
+      WaypointOut o;
+      o.x = r0.x;
+      o.y = r0.y;
+      o.heading = r0.heading;
+      o.width = m.lane_width[SMX_BCHK(17, lane0, m.n_lanes)];
+      o.speed = m.lane_speed[lane0];
+      o.lane = lane0;
+      emit(0, o);
     }
     return 1;
   }
 
   // ---- pass 2: emit
   const int n_emit = min(n, max_emit);
+  if (n_emit <= 0) return n;
   const double step = D / (double)(n - 1);  // np.linspace(0, D, n)
   int i = 0;                                // next waypoint to emit
   double t = 0.0;
-  // current knot j
-  double jx = k0x, jy = k0y, jh = m.lp_heading[start], jcum = 0.0;
+  double jx = k0x, jy = k0y, jh = r0.heading, jcum = 0.0;
   int jlane = lane0;
   int strict_lane = lane0;  // lane of the last knot with cum strictly below jcum (knot 0 if none)
   Unwrap uw;
   uw.start(jh);
-  int level = 0;
-  int lp = start;
-  for (int hop = 1; hop < n && i < n_emit; ++hop) {
-    int nx = walk_next(m, f, bs, level, lp);
-    lp = nx;
-    bool knot = (!m.lp_inferred[nx]) || (hop == n - 1);
-    if (!knot) continue;
-    // next knot j+1
-    double qx = m.lp_x[nx], qy = m.lp_y[nx];
-    double ex = qx - jx, ey = qy - jy;
-    double qcum = jcum + sqrt(ex * ex + ey * ey);
-    double qh = uw.push(m.lp_heading[nx]);
-    int qlane = m.lp_lane[nx];
+  smx_lp_rec q = (nk > 0) ? load_lp(m, knots[0], 44) : r0;
+  for (int k = 0; k < nk && i < n_emit; ++k) {
+    const smx_lp_rec cur = q;
+    if (k + 1 < nk) q = load_lp(m, knots[(k + 1) * kstride], 45);  // prefetch the next knot
+    const double qx = cur.x, qy = cur.y;
+    const double ex = qx - jx, ey = qy - jy;
+    const double qcum = jcum + sqrt(ex * ex + ey * ey);
+    const double qh = uw.push(cur.heading);
+    const int qlane = cur.lane;
     // waypoints with jcum <= t < qcum interpolate on [j, j+1]
     while (i < n_emit && t < qcum) {
-      WaypointOut w;
+      WaypointOut o;
       int dl;
       if (t == jcum) {
-        w.x = jx;
-        w.y = jy;
-        w.heading = jh;
-        w.width = m.lane_width[jlane];
-        w.speed = m.lane_speed[jlane];
+        o.x = jx;
+        o.y = jy;
+        o.heading = jh;
+        o.width = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)];
+        o.speed = m.lane_speed[jlane];
         dl = strict_lane;
       } else {
-        double den = qcum - jcum, dt_ = t - jcum;
-        w.x = ((qx - jx) / den) * dt_ + jx;
-        w.y = ((qy - jy) / den) * dt_ + jy;
-        w.heading = ((qh - jh) / den) * dt_ + jh;
-        double wj = m.lane_width[jlane], sj = m.lane_speed[jlane];
-        w.width = ((m.lane_width[qlane] - wj) / den) * dt_ + wj;
-        w.speed = ((m.lane_speed[qlane] - sj) / den) * dt_ + sj;
+        const double den = qcum - jcum, dt_ = t - jcum;
+        o.x = ((qx - jx) / den) * dt_ + jx;
+        o.y = ((qy - jy) / den) * dt_ + jy;
+        o.heading = ((qh - jh) / den) * dt_ + jh;
+        const double wj = m.lane_width[jlane], sj = m.lane_speed[jlane];
+        o.width = ((m.lane_width[qlane] - wj) / den) * dt_ + wj;
+        o.speed = ((m.lane_speed[qlane] - sj) / den) * dt_ + sj;
         dl = jlane;
       }
-      w.heading = wrap_heading(w.heading);
-      w.lane = dl;
-      emit(i, w);
+      o.heading = wrap_heading(o.heading);
+      o.lane = dl;
+      emit(i, o);
       ++i;
       t = (i == n - 1) ? D : (double)i * step;
     }
@@ -414,39 +568,51 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
   }
   // waypoints at (or beyond) the last knot
   while (i < n_emit) {
-    WaypointOut w;
-    w.x = jx;
-    w.y = jy;
-    w.heading = wrap_heading(jh);
-    w.width = m.lane_width[jlane];
-    w.speed = m.lane_speed[jlane];
-    w.lane = (t > jcum) ? jlane : strict_lane;
-    emit(i, w);
+    WaypointOut o;
+    o.x = jx;
+    o.y = jy;
+    o.heading = wrap_heading(jh);
+    o.width = m.lane_width[jlane];
+    o.speed = m.lane_speed[jlane];
+    o.lane = (t > jcum) ? jlane : strict_lane;
+    emit(i, o);
     ++i;
     t = (i == n - 1) ? D : (double)i * step;
   }
   return n;
 }
 
-// Resolution of the road whose lanes seed the paths (sumo_road_network.py:815-882) for an agent
-// with an empty route (EndlessGoal): junction lanes pin the route to [junction road, next road].
-struct PathSeed {
-  int road;        // road whose lanes are enumerated
-  RouteFilter f;   // route filter for the walks
+// ---------------------------------------------------------------------------------
+// path seeds: the road whose lanes start the paths, the route filter, and the start lanepoint
+// on each of its lanes (sumo_road_network.py:815-882, Lane._waypoint_paths_at :429-446)
+// ---------------------------------------------------------------------------------
+#define SMX_SEED_LANES 4
+struct PathSeeds {
+  int road;                    // -1: none found
+  RouteFilter f;
+  int n_lanes;                 // lanes of `road`
+  int start[SMX_SEED_LANES];   // start lanepoint per lane (first SMX_SEED_LANES lanes)
 };
 
-__device__ inline PathSeed resolve_path_seed(const MapDev& m, double px, double py, double heading,
-                                             double within_radius, bool has_route_object) {
-  PathSeed s;
+// has_route_object: the agent carries a (possibly empty) Route — the controller and the
+// waypoints sensor do; TripMeterSensor's constructor query does not.
+__device__ __noinline__ PathSeeds compute_path_seeds(const MapDev& m, double px, double py, double heading,
+                                               double within_radius, bool has_route_object) {
+  PathSeeds s;
   s.f.n = 0;
   s.road = -1;
+  s.n_lanes = 0;
+#pragma unroll
+  for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
+  Top10 t;
+  nearest10(m, px, py, t);
+  bool routed = false;
   if (has_route_object) {
     // _resolve_in_junction (:842-860)
-    int lp = closest_lanepoint(m, px, py, heading, -1.0);
+    int lp = pick_closest(m, t, heading, -1.0);
     if (lp >= 0) {
-      int lane = m.lp_lane[lp];
-      int road = m.lane_road[lane];
-      if (m.road_is_junction[road]) {
+      int road = m.lane_road[SMX_BCHK(19, m.lp_rec[lp].lane, m.n_lanes)];
+      if (m.road_is_junction[SMX_BCHK(20, road, m.n_roads)]) {
         s.f.n = 1;
         s.f.road[0] = road;
         int nr = m.road_out_road[road];
@@ -454,26 +620,48 @@ __device__ inline PathSeed resolve_path_seed(const MapDev& m, double px, double 
           s.f.n = 2;
           s.f.road[1] = nr;
         }
-        // _waypoint_paths_along_route (:862-882): nearest lanepoint over the route roads
+        // _waypoint_paths_along_route (:862-882): nearest lanepoint over the route roads; the
+        // reference compares np.linalg.norm distances, first minimum wins
+        int idx4[4];
+        double d24[4];
+        closest_filtered4(m, px, py, s.f.road, s.f.n, true, idx4, d24);
         double bd = SMX_INF;
         int best = -1;
         for (int k = 0; k < s.f.n; ++k) {
-          double d2;
-          int c = closest_lanepoint_filtered(m, px, py, s.f.road[k], true, &d2);
-          // reference compares np.linalg.norm distances; sqrt is monotone and the first
-          // minimum wins
-          double d = sqrt(d2);
-          if (c >= 0 && d < bd) {
+          double d = sqrt(d24[k]);
+          if (idx4[k] >= 0 && d < bd) {
             bd = d;
-            best = c;
+            best = idx4[k];
           }
         }
-        s.road = best >= 0 ? m.lane_road[m.lp_lane[best]] : -1;
-        return s;
+        s.road = best >= 0 ? m.lane_road[m.lp_rec[best].lane] : -1;
+        routed = true;
       }
     }
   }
-  int lp = closest_lanepoint(m, px, py, heading, within_radius);
-  s.road = lp >= 0 ? m.lane_road[m.lp_lane[lp]] : -1;
+  if (!routed) {
+    int lp = pick_closest(m, t, heading, within_radius);
+    s.road = lp >= 0 ? m.lane_road[m.lp_rec[lp].lane] : -1;
+  }
+  if (s.road >= 0) {
+    const int la = m.road_lane_off[SMX_BCHK(21, s.road, m.n_roads)], lb = m.road_lane_off[s.road + 1];
+    s.n_lanes = lb - la;
+    int keys[4] = {-9, -9, -9, -9};
+    const int nk = min(s.n_lanes, SMX_SEED_LANES);
+    for (int q = 0; q < nk; ++q) keys[q] = m.road_lanes[la + q];
+    closest_filtered4(m, px, py, keys, nk, false, s.start, nullptr);
+  }
   return s;
+}
+
+// Start lanepoint on lane number `li` (position within the road) of the seed road.
+__device__ __forceinline__ int seed_start(const MapDev& m, const PathSeeds& s, int li, double px, double py) {
+  if (li < SMX_SEED_LANES) {
+    // static selection keeps the array in registers
+    return li == 0 ? s.start[0] : (li == 1 ? s.start[1] : (li == 2 ? s.start[2] : s.start[3]));
+  }
+  int key[4] = {m.road_lanes[m.road_lane_off[s.road] + li], -9, -9, -9};
+  int idx[4];
+  closest_filtered4(m, px, py, key, 1, false, idx, nullptr);
+  return idx[0];
 }

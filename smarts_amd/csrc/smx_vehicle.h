@@ -113,11 +113,13 @@ struct ControlOut {
 // tests/test_host_logic.py.
 __device__ inline ControlOut lane_following_control(const MapDev& m, const VehState& s, CtrlState& cs, double dt,
                                                     double target_speed, int lane_change,
-                                                    double heading_error_gain, double lateral_error_gain) {
+                                                    double heading_error_gain, double lateral_error_gain,
+                                                    const PathSeeds& seed, int* knots, int kstride) {
   const double px = s.x, py = s.y;
   const double speed = vehicle_speed(s);
-  // ---- waypoint paths, lookahead 16, route = the agent's (empty) route (:96-98)
-  PathSeed seed = resolve_path_seed(m, px, py, s.heading, 5.0, true);
+  // ---- waypoint paths, lookahead 16, route = the agent's (empty) route (:96-98).  `seed` holds
+  // the start road / route filter / start lanepoints for this pose (computed by the previous
+  // observation, which queried the map at the same pose).
   ControlOut out;
   out.throttle = cs.throttle;
   out.brake = 0.0;
@@ -126,19 +128,17 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
 
   // pass A: the path nearest to the vehicle by its first waypoint (find_current_lane :367-374);
   // paths are numbered in the reference's order: lanes by index, branches depth-first.
-  const int la = m.road_lane_off[seed.road], lb = m.road_lane_off[seed.road + 1];
   int n_paths = 0;
   int best_path = 0;
   double best_d = SMX_INF;
-  for (int li = la; li < lb; ++li) {
-    int lane = m.road_lanes[li];
-    int start = closest_lanepoint_filtered(m, px, py, lane, false);
+  for (int li = 0; li < seed.n_lanes; ++li) {
+    int start = seed_start(m, seed, li, px, py);
     if (start < 0) continue;
     BranchState bs;
     bs.reset();
     do {
       double fx = 0.0, fy = 0.0;
-      equally_spaced_path(m, seed.f, bs, start, 16, px, py, 1, [&](int, const WaypointOut& w) {
+      equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 1, [&](int, const WaypointOut& w) {
         fx = w.x;
         fy = w.y;
       });
@@ -165,15 +165,15 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
   {
     int idx = 0;
     bool found = false;
-    for (int li = la; li < lb && !found; ++li) {
-      int lane = m.road_lanes[li];
-      int start = closest_lanepoint_filtered(m, px, py, lane, false);
+    for (int li = 0; li < seed.n_lanes && !found; ++li) {
+      int start = seed_start(m, seed, li, px, py);
       if (start < 0) continue;
       BranchState bs;
       bs.reset();
       do {
         if (idx == want) {
-          wp_n = equally_spaced_path(m, seed.f, bs, start, 16, px, py, 17, [&](int i, const WaypointOut& w) {
+          wp_n = equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 17,
+                                     [&](int i, const WaypointOut& w) {
 #pragma unroll
             for (int k = 0; k < 17; ++k)
               if (k == i) ewma_acc[k] = w.heading;
@@ -203,7 +203,7 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
           break;
         }
         // not the wanted path: walk it only to discover its branchings
-        equally_spaced_path(m, seed.f, bs, start, 16, px, py, 0, [&](int, const WaypointOut&) {});
+        equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 0, [&](int, const WaypointOut&) {});
         ++idx;
       } while (bs.advance());
     }

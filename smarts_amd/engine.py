@@ -124,23 +124,29 @@ _MAP_ARRAYS = [
     ("lane_length", np.float64), ("lane_in_junction", np.uint8), ("lane_shape_off", np.int32),
     ("shape_x", np.float64), ("shape_y", np.float64), ("lane_out_off", np.int32), ("lane_out_idx", np.int32),
     ("road_lane_off", np.int32), ("road_lanes", np.int32), ("road_is_junction", np.uint8),
-    ("road_out_road", np.int32), ("lp_x", np.float64), ("lp_y", np.float64), ("lp_heading", np.float64),
-    ("lp_dirx", np.float64), ("lp_diry", np.float64), ("lp_lane", np.int32), ("lp_inferred", np.uint8),
-    ("lp_next_off", np.int32), ("lp_next_idx", np.int32), ("lpg_off", np.int32), ("lpg_idx", np.int32),
-    ("seg_lane", np.int32), ("seg_v0", np.int32), ("sg_off", np.int32), ("sg_idx", np.int32),
+    ("road_out_road", np.int32), ("lpg_off", np.int32), ("sg_off", np.int32),
 ]
 
 
 def map_tables_struct(cm: CompiledMap):
     """Fill ``smx_map_tables`` with pointers into (kept-alive) contiguous numpy arrays."""
+    from .map_compiler import pack_tables
+
     keep = []
     t = nat.SmxMapTables()
+    packed = pack_tables(cm)
     t.n_lanes, t.n_roads = cm.n_lanes, len(cm.road_ids)
-    t.n_lanepoints, t.n_shape_pts, t.n_segments = cm.n_lanepoints, len(cm.shape_x), len(cm.seg_lane)
+    t.n_lanepoints, t.n_shape_pts, t.n_succ = cm.n_lanepoints, len(cm.shape_x), len(packed["succ_rec"])
     for name, dt in _MAP_ARRAYS:
         arr = np.ascontiguousarray(getattr(cm, name), dtype=dt)
         if arr.size == 0:
             arr = np.zeros(1, dtype=dt)
+        keep.append(arr)
+        setattr(t, name, arr.ctypes.data)
+    for name in ("lp_rec", "succ_rec", "lpg_pts", "sg_rec"):
+        arr = np.ascontiguousarray(packed[name])
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=arr.dtype)
         keep.append(arr)
         setattr(t, name, arr.ctypes.data)
     t.lpg_x0, t.lpg_y0, t.lpg_cell = float(cm.lpg_origin[0]), float(cm.lpg_origin[1]), float(cm.lpg_cell)
@@ -200,6 +206,8 @@ class BatchedSim:
         st.env_ticks, st.env_done_count = self.env_ticks.data_ptr(), self.env_done_count.data_ptr()
         st.env_episode = self.env_episode.data_ptr()
         st.driven_path = self.driven_path.data_ptr() if need_ring else None
+        self.seed_cache = torch.full((nat.SEED_COUNT, E, N), -1, dtype=torch.int32, device=dev)
+        st.seed_cache = self.seed_cache.data_ptr()
         self._st = st
 
         # ---- spawns ----
@@ -265,7 +273,7 @@ class BatchedSim:
         return per
 
     def state_bytes_per_agent_step(self) -> int:
-        return nat.S_COUNT * 8 + 4 + 4
+        return nat.S_COUNT * 8 + 4 + 4 + nat.SEED_COUNT * 4
 
     def reset(self, env_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         mask_ptr = None

@@ -388,3 +388,84 @@ def compile_map(net: SumoNet, lanepoint_spacing: float = 1.0, default_lane_width
         max_fanout=int(max((len(n) for n in nexts), default=1)),
         shifted_by=tuple(net.shifted_by),
     )
+
+
+# --------------------------------------------------------------------------------------
+# packed device records (what smx_load_map uploads)
+# --------------------------------------------------------------------------------------
+LP_REC = np.dtype(
+    [("x", "<f8"), ("y", "<f8"), ("heading", "<f8"), ("dirx", "<f8"), ("diry", "<f8"), ("lane", "<i4"),
+     ("next_off", "<i4"), ("next0", "<i4"), ("n_next", "<u2"), ("inferred", "u1"), ("flags", "u1"),
+     ("knot_next", "<i4"), ("knot_hops", "<i4")], align=False)
+SUCC_REC = np.dtype([("idx", "<i4"), ("lane", "<i4"), ("knot", "<i4"), ("hops", "<i4")], align=False)
+PT_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("idx", "<i4"), ("lane", "<i4")], align=False)
+SEG_REC = np.dtype([("x1", "<f8"), ("y1", "<f8"), ("x2", "<f8"), ("y2", "<f8"), ("thr", "<f8"), ("lane", "<i4"),
+                    ("pad", "<i4")], align=False)
+assert LP_REC.itemsize == 64 and SUCC_REC.itemsize == 16 and PT_REC.itemsize == 24 and SEG_REC.itemsize == 48
+
+
+def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
+    """Array-of-records forms of the lanepoint graph and the two grids.
+
+    * ``lp_rec``: one 64-byte record per lanepoint = one cache line per hop of a path walk,
+      with *knot skip-links*: ``knot_next`` / ``knot_hops`` give the next non-inferred
+      lanepoint down the (single-successor) chain, so a 32-hop walk touches only the shape
+      points it passes.  Interpolated lanepoints of one segment have consecutive indices
+      (``lanepoints.py:462-515`` appends them in one loop), which lets the walk address the
+      point it stops on directly; ``flags & 1`` certifies that for the record's chain.
+    * ``succ_rec``: per successor of a branching lanepoint: first point, its lane, and the
+      knot that branch reaches.
+    * ``lpg_pts`` / ``sg_rec``: the grid cells' members stored by value, contiguous per cell,
+      so a cell scan is one stream instead of an index chase.
+    """
+    n = cm.n_lanepoints
+    off, idx = cm.lp_next_off, cm.lp_next_idx
+    inferred = cm.lp_inferred.astype(bool)
+    rec = np.zeros(n, dtype=LP_REC)
+    rec["x"], rec["y"], rec["heading"] = cm.lp_x, cm.lp_y, cm.lp_heading
+    rec["dirx"], rec["diry"], rec["lane"] = cm.lp_dirx, cm.lp_diry, cm.lp_lane
+    rec["next_off"] = off[:-1]
+    rec["n_next"] = np.diff(off)
+    rec["inferred"] = cm.lp_inferred
+    rec["next0"] = -1
+    rec["knot_next"] = -1
+    rec["knot_hops"] = 0
+
+    def chase(first):
+        """From `first`, follow single successors until a non-inferred point: (knot, hops, consecutive)."""
+        hops, cur, consecutive = 1, first, True
+        while inferred[cur]:
+            assert off[cur + 1] - off[cur] == 1, "an interpolated lanepoint must have exactly one successor"
+            nxt = int(idx[off[cur]])
+            if inferred[nxt] and nxt != cur + 1:
+                consecutive = False
+            cur = nxt
+            hops += 1
+        return cur, hops, consecutive
+
+    succ = np.zeros(len(idx), dtype=SUCC_REC)
+    for i in range(n):
+        a, b = int(off[i]), int(off[i + 1])
+        if b - a >= 1:
+            rec["next0"][i] = idx[a]
+        for k in range(a, b):
+            first = int(idx[k])
+            knot, hops, ok = chase(first)
+            succ[k] = (first, cm.lp_lane[first], knot, hops)
+            if k == a:
+                rec["knot_next"][i], rec["knot_hops"][i] = knot, hops
+                rec["flags"][i] = 1 if ok else 0
+            elif not ok:
+                rec["flags"][i] = 0
+    # grid cells by value
+    pts = np.zeros(len(cm.lpg_idx), dtype=PT_REC)
+    pts["idx"] = cm.lpg_idx
+    pts["x"], pts["y"], pts["lane"] = cm.lp_x[cm.lpg_idx], cm.lp_y[cm.lpg_idx], cm.lp_lane[cm.lpg_idx]
+    seg = np.zeros(len(cm.sg_idx), dtype=SEG_REC)
+    v0 = cm.seg_v0[cm.sg_idx]
+    lane = cm.seg_lane[cm.sg_idx]
+    seg["x1"], seg["y1"], seg["x2"], seg["y2"] = cm.shape_x[v0], cm.shape_y[v0], cm.shape_x[v0 + 1], cm.shape_y[v0 + 1]
+    # road_with_point threshold, the reference's expression (sumo_road_network.py:707)
+    seg["thr"] = np.array([0.5 * float(w) + 1e-1 for w in cm.lane_width[lane]])
+    seg["lane"] = lane
+    return dict(lp_rec=rec, succ_rec=succ, lpg_pts=pts, sg_rec=seg)
