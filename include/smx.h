@@ -173,13 +173,15 @@ enum {
   SMX_S_LV0_LONG, SMX_S_LV0_LAT, SMX_S_AV0_Z,           /* AccelerometerSensor history (sensors.py:1046-1087) */
   SMX_S_LV1_LONG, SMX_S_LV1_LAT, SMX_S_AV1_Z,
   SMX_S_PATH_SUM,                        /* DrivenPathSensor running window length (sensors.py:855-877) */
+  SMX_S_PREV_X, SMX_S_PREV_Y,            /* position at the previous observation (driven-path segment) */
   SMX_S_COUNT
 };
 enum {
   SMX_F_ALIVE = 1 << 0,
   SMX_F_MCL_SET = 1 << 1,
   SMX_F_TRIP_HAS_WP = 1 << 2,
-  SMX_F_HIST_SHIFT = 3 /* bits 3-4: accelerometer samples held (0..2) */
+  SMX_F_HIST_SHIFT = 3, /* bits 3-4: accelerometer samples held (0..2) */
+  SMX_F_FIRST = 1 << 5  /* vehicle was just (re)created: its next observation is a reset observation */
 };
 
 #define SMX_DRIVEN_PATH_LEN 500 /* DrivenPathSensor deque, sensors.py:838 */
@@ -197,8 +199,15 @@ typedef struct smx_state {
                           found by the last observation at the vehicle's current pose; the
                           next tick's controller queries the map at that same pose
                           (lane_following_controller.py:96-98) and reuses them     */
+  int32_t* facts_i32;  /* [SMX_FACT_I_COUNT][E*N] per-tick map facts of each vehicle (scan kernel
+                          -> observe kernels): nearest lane, road flags, trip-meter seed   */
+  double* facts_f64;   /* [SMX_FACT_F_COUNT][E*N]: nearest-lane distance                     */
+  int32_t* env_reset_pending; /* [E] set by the observe kernel when auto_reset fires        */
 } smx_state;
 #define SMX_SEED_COUNT 9 /* road, filter n, filter roads x2, lane count, start lanepoint x4 */
+enum { SMX_FI_LANE = 0, SMX_FI_FLAGS, SMX_FI_TRIP_START, SMX_FI_OBS_START, SMX_FACT_I_COUNT };
+enum { SMX_FF_LANE_DIST = 0, SMX_FACT_F_COUNT };
+enum { SMX_FACT_ON_ROAD = 1 << 0, SMX_FACT_CORNER_SHIFT = 1 /* bits 1-4: corner q on road */ };
 
 /* Spawn table: episode k of env e starts from row (k mod episodes).
  * x, y = vehicle centre, heading in reference convention, speed m/s. */

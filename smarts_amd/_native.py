@@ -24,10 +24,11 @@ EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way"
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
                 "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
-                "LV1_LAT", "AV1_Z", "PATH_SUM"]
+                "LV1_LAT", "AV1_Z", "PATH_SUM", "PREV_X", "PREV_Y"]
 S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
-F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT = 1, 2, 4, 3
+F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST = 1, 2, 4, 3, 32
+FACT_I_COUNT, FACT_F_COUNT = 4, 1
 DRIVEN_PATH_LEN = 500
 SEED_COUNT = 9
 EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,
@@ -67,7 +68,8 @@ class SmxMapTables(C.Structure):
 
 class SmxState(C.Structure):
     _fields_ = [("f64", _p), ("flags", _p), ("steps", _p), ("env_ticks", _p), ("env_done_count", _p),
-                ("env_episode", _p), ("driven_path", _p), ("seed_cache", _p)]
+                ("env_episode", _p), ("driven_path", _p), ("seed_cache", _p), ("facts_i32", _p), ("facts_f64", _p),
+                ("env_reset_pending", _p)]
 
 
 class SmxSpawns(C.Structure):

@@ -29,11 +29,26 @@ __device__ int smx_dbg_aux[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SMX_BCHK(site, idx, n) (idx)
 #endif
 
+// Developer build (-DSMX_DEBUG_TIMING): per-phase wave-clock accumulation.
+#ifdef SMX_DEBUG_TIMING
+__device__ unsigned long long smx_prof[24];
+#define SMX_TSTAMP(var) unsigned long long var = wall_clock64()
+#define SMX_TACC(slot, t0, t1) \
+  do { if ((threadIdx.x & 63) == 0) atomicAdd(&smx_prof[slot], (t1) - (t0)); } while (0)
+#else
+#define SMX_TSTAMP(var)
+#define SMX_TACC(slot, t0, t1)
+#endif
+
 // ---------------------------------------------------------------------------------
 // angle helpers (reference smarts/core/utils/math.py, smarts/core/coordinates.py)
 // ---------------------------------------------------------------------------------
 // Python / numpy float modulo for a positive divisor.
 __device__ __forceinline__ double py_mod(double a, double b) {
+  // |a| < b is the common case on this path (angles): the remainder is then `a` itself, or
+  // `a + b` for negative `a` — exactly what fmod-then-adjust yields, without the slow fmod.
+  if (a >= 0.0 && a < b) return a;
+  if (a < 0.0 && a > -b) return a + b;
   double m = fmod(a, b);
   if (m != 0.0 && m < 0.0) m += b;
   return m;

@@ -1,17 +1,22 @@
 // smx_kernels.hip — the per-tick kernels of the SMARTS hot path on gfx950, and the C-ABI.
 //
-// One thread per vehicle slot, one workgroup per group of whole environment instances, so
-// that everything an instance's vehicles exchange in a tick (poses for the neighbourhood
-// sensor and the collision check) goes through LDS behind one workgroup barrier.  Envs are
-// independent (reference: one process per env, parallel_env.py:96-122), so there is no
-// inter-workgroup communication at all.
+// A tick = SMARTS._step (smarts.py:236-327) for every environment instance of the shard, as four
+// small kernels on one stream (each stage has its own natural thread mapping; together they
+// stay far below the register pressure of one fused kernel):
 //
-// Tick order = SMARTS._step (smarts.py:236-327):
-//   A controllers   (_perform_agent_actions, smarts.py:1233-1263)
-//   B physics       (_step_pybullet, smarts.py:923-931)
-//   C collisions    (_process_collisions, smarts.py:1270-1291)
-//   D sensors       (Sensors.observe, sensors.py:238-396; events :443-594)
-//   E teardown / auto-reset (smarts.py:314; parallel_env.py:303-309)
+//   k_control    1 thread / vehicle     A controllers (_perform_agent_actions, smarts.py:1233-1263)
+//                                       B physics     (_step_pybullet, smarts.py:923-931)
+//   k_scan       8 lanes  / vehicle     map sweeps at the new pose: nearest lane / road_with_point
+//                                       at centre + 4 corners, 10 nearest lanepoints, path seeds
+//   k_waypoints  4 lanes  / vehicle     D1 waypoint paths (one lane per kept path), LDS-staged
+//                                       so that the dense observation rows leave as full lines;
+//                                       trip meter / reward
+//   k_observe    1 thread / vehicle,    C collisions, D2 neighbours, ego block, accelerometer,
+//                whole envs / workgroup driven path, events, done, teardown, dones["__all__"]
+//
+// followed, for envs whose episode ended under auto_reset (parallel_env.py:303-309), by
+// k_reset + the last three kernels restricted to the re-created vehicles.  Envs are independent
+// (reference: one process per env, parallel_env.py:96-122): no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -22,10 +27,13 @@
 #include <string>
 #include <vector>
 
+#include "smx_scan.h"
 #include "smx_vehicle.h"
 
 #define SMX_BLOCK 64
 #define SMX_COLLISION_LEEWAY 0.05  // chassis.py:75-78
+#define SMX_WP_LANES 4             // lanes of a wavefront that share one vehicle in k_waypoints
+#define SMX_POSE_SCAN_RADIUS 10.0
 
 struct KernelArgs {
   smx_config cfg;
@@ -34,22 +42,16 @@ struct KernelArgs {
   smx_spawns sp;
   smx_outputs out;
   const int8_t* actions;
-  const uint8_t* env_mask;  // reset kernel only
+  const uint8_t* env_mask;  // k_reset: explicit mask (NULL = use env_reset_pending / all)
   const double* lidar_rays;
-  int envs_per_block;
+  int first_only;           // restrict to vehicles carrying SMX_F_FIRST (reset observations)
+  int keep_reward_done;     // auto-reset: the terminal step's reward / done / env_done stay
+  int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
-  int debug_skip;  // developer ablation mask (SMX_DEBUG_SKIP env var), 0 in production
+  int debug_skip;
 };
 
-// Pose block shared by the vehicles of the envs of one workgroup (LDS).
-struct __align__(16) SharedPose {
-  double x, y, heading, speed;
-  double lane_dist;  // centre-line distance of `lane`
-  int lane;          // nearest lane within SMX_POSE_SCAN_RADIUS, -1 none
-  int alive;
-  int on_road;       // road_with_point(centre) is not None
-  int corner_mask;   // bit q: road_with_point(bounding-box corner q) is not None
-};
+#define SF(field) a.st.f64[(size_t)(field) * total + gid]
 
 // ---------------------------------------------------------------------------------
 // oriented-box proximity (substitution for pybullet getClosestPoints)
@@ -84,7 +86,7 @@ __device__ __forceinline__ double seg_point_dist2(double px, double py, double a
   return ex * ex + ey * ey;
 }
 
-__device__ __noinline__ bool boxes_within(double ax, double ay, double ah, double bx, double by, double bh, double len,
+__device__ inline bool boxes_within(double ax, double ay, double ah, double bx, double by, double bh, double len,
                                     double wid, double leeway) {
   // broad phase: circumscribed circles
   double dx = ax - bx, dy = ay - by;
@@ -125,50 +127,6 @@ __device__ __noinline__ bool boxes_within(double ax, double ay, double ah, doubl
   return false;
 }
 
-// ---------------------------------------------------------------------------------
-// state load / store (struct-of-arrays, coalesced across the wave)
-// ---------------------------------------------------------------------------------
-#define SF(field) a.st.f64[(size_t)(field) * total + gid]
-
-__device__ __forceinline__ void zero_outputs(const KernelArgs& a, size_t gid) {
-  const smx_config& c = a.cfg;
-  const smx_outputs& o = a.out;
-  for (int k = 0; k < 3; ++k) o.ego_pos[gid * 3 + k] = 0.0;
-  for (int k = 0; k < SMX_EGO_F32_COUNT; ++k) o.ego_f32[gid * SMX_EGO_F32_COUNT + k] = 0.0f;
-  o.ego_lane[gid * 2] = -1;
-  o.ego_lane[gid * 2 + 1] = -1;
-  for (int k = 0; k < SMX_EV_COUNT; ++k) o.events[gid * SMX_EV_COUNT + k] = 0;
-  o.reward[gid] = 0.0;
-  if (c.sensors & SMX_SENSOR_WAYPOINTS) {
-    size_t per = (size_t)c.wp_paths * c.wp_len;
-    for (size_t k = 0; k < per; ++k) {
-      size_t q = gid * per + k;
-      o.wp_pos[q * 3] = 0.0;
-      o.wp_pos[q * 3 + 1] = 0.0;
-      o.wp_pos[q * 3 + 2] = 0.0;
-      o.wp_heading[q] = 0.0f;
-      o.wp_lane_width[q] = 0.0f;
-      o.wp_speed_limit[q] = 0.0f;
-      o.wp_lane_index[q] = 0;
-      o.wp_lane_id[q] = -1;
-    }
-    for (int k = 0; k <= c.wp_paths; ++k) o.wp_count[gid * (c.wp_paths + 1) + k] = 0;
-  }
-  if (c.sensors & SMX_SENSOR_NEIGHBORS) {
-    for (int k = 0; k < c.nb_max; ++k) {
-      size_t q = gid * c.nb_max + k;
-      o.nb_pos[q * 3] = o.nb_pos[q * 3 + 1] = o.nb_pos[q * 3 + 2] = 0.0;
-      o.nb_box[q * 3] = o.nb_box[q * 3 + 1] = o.nb_box[q * 3 + 2] = 0.0f;
-      o.nb_heading[q] = 0.0f;
-      o.nb_speed[q] = 0.0f;
-      o.nb_lane_index[q] = 0;
-      o.nb_lane_id[q] = -1;
-      o.nb_slot[q] = -1;
-    }
-    o.nb_count[gid] = 0;
-  }
-}
-
 
 __device__ __forceinline__ void store_seeds(const KernelArgs& a, size_t gid, size_t total, const PathSeeds& s) {
   int32_t* c = a.st.seed_cache;
@@ -198,6 +156,17 @@ __device__ __forceinline__ PathSeeds load_seeds(const KernelArgs& a, size_t gid,
   return s;
 }
 
+__device__ __forceinline__ VehState load_vehicle(const KernelArgs& a, size_t gid, size_t total) {
+  VehState s;
+  s.x = SF(SMX_S_X);
+  s.y = SF(SMX_S_Y);
+  s.heading = SF(SMX_S_HEADING);
+  s.u = SF(SMX_S_U);
+  s.v = SF(SMX_S_V);
+  s.r = SF(SMX_S_R);
+  s.delta = SF(SMX_S_DELTA);
+  return s;
+}
 // ---------------------------------------------------------------------------------
 // lane heading at the centre-line point closest to (px, py):
 //   Lane.center_pose_at_point(point).heading  (road_map.py:390-396)
@@ -245,7 +214,7 @@ __device__ inline void position_at_shape_offset(const MapDev& m, int v0, int v1,
   oy = m.shape_y[v1 - 1];
 }
 
-__device__ __noinline__ double lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
+__device__ inline double lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
   const int v0 = m.lane_shape_off[SMX_BCHK(31, lane, m.n_lanes)], v1 = m.lane_shape_off[lane + 1];
   // offset_along_lane
   double offset;
@@ -267,6 +236,18 @@ __device__ __noinline__ double lane_heading_at_point(const MapDev& m, int lane, 
       for (int v = v0; v + 1 < v1; ++v) {
         double x1 = m.shape_x[v], y1 = m.shape_y[v], x2 = m.shape_x[v + 1], y2 = m.shape_y[v + 1];
         double d = euclid(x1, y1, x2, y2);
+        {
+          // a segment whose bounding box is farther than the best distance so far cannot lower
+          // the minimum (the first minimum wins, so ties need no visit either); `seen` still
+          // advances
+          const double gx = fmax(fmax(fmin(x1, x2) - px, px - fmax(x1, x2)), 0.0);
+          const double gy = fmax(fmax(fmin(y1, y2) - py, py - fmax(y1, y2)), 0.0);
+          const double keep = min_dist + 1e-6;
+          if (gx * gx + gy * gy > keep * keep) {
+            seen += d;
+            continue;
+          }
+        }
         double u = ((px - x1) * (x2 - x1)) + ((py - y1) * (y2 - y1));
         double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
         double fx, fy;
@@ -301,347 +282,90 @@ __device__ __noinline__ double lane_heading_at_point(const MapDev& m, int lane, 
   return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
 }
 
-// ---------------------------------------------------------------------------------
-// phase D: Sensors.observe for one vehicle (sensors.py:238-396, 443-594)
-// ---------------------------------------------------------------------------------
-struct ObserveCtx {
-  size_t gid, total;
-  int slot, n_veh;
-  const SharedPose* env_pose;  // the env's vehicles, [n_veh]
-  bool collided;
-  int steps;      // SensorState._step after this observation's increment
-  int env_ticks;  // ticks since reset (elapsed_sim_time / dt)
-  double prev_x, prev_y;  // position at the previous observation
-  bool first;     // observation produced by a reset
-  bool write_reward;
-  int* knots;     // per-thread knot scratch (LDS), stride SMX_BLOCK
-};
 
-__device__ inline bool observe_vehicle(const KernelArgs& a, const ObserveCtx& k, const VehState& s, int& flags) {
+// =================================================================================
+// k_control: controllers + physics, one thread per vehicle
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
-  const smx_outputs& o = a.out;
   const MapDev& m = a.map;
-  const size_t gid = k.gid, total = k.total;
-  const double px = s.x, py = s.y;
-  const double speed = vehicle_speed(s);
-  double lng, lat;
-  long_lat_speed(s, lng, lat);
-  const SharedPose& me = k.env_pose[k.slot];
-
-  // ---- ego lane (sensors.py:277-285): nearest lane within max(10, 2 * default lane width)
-  const int ego_lane = (me.lane >= 0 && me.lane_dist < fmax(10.0, 2.0 * m.default_lane_width)) ? me.lane : -1;
-
-  // ---- ego vehicle state (sensors.py:314-329; read-back of chassis.py:493-566)
-  o.ego_pos[gid * 3 + 0] = px;
-  o.ego_pos[gid * 3 + 1] = py;
-  o.ego_pos[gid * 3 + 2] = SMX_BASE_HEIGHT;
-  float* ef = o.ego_f32 + gid * SMX_EGO_F32_COUNT;
-  ef[SMX_EGO_HEADING] = (float)wrap_heading(s.heading);
-  ef[SMX_EGO_SPEED] = (float)speed;
-  ef[SMX_EGO_STEERING] = (float)(-s.delta);
-  ef[SMX_EGO_YAW_RATE] = (float)vec_to_radians(0.0, 0.0);  // chassis.py:552-556 on a planar body
-  ef[SMX_EGO_LIN_VEL + 0] = (float)lng;
-  ef[SMX_EGO_LIN_VEL + 1] = (float)lat;
-  ef[SMX_EGO_LIN_VEL + 2] = 0.0f;
-  ef[SMX_EGO_ANG_VEL + 0] = 0.0f;
-  ef[SMX_EGO_ANG_VEL + 1] = 0.0f;
-  ef[SMX_EGO_ANG_VEL + 2] = (float)s.r;
-  ef[SMX_EGO_BOX + 0] = (float)SMX_CHASSIS_LENGTH;
-  ef[SMX_EGO_BOX + 1] = (float)SMX_CHASSIS_WIDTH;
-  ef[SMX_EGO_BOX + 2] = (float)SMX_CHASSIS_HEIGHT;
-  o.ego_lane[gid * 2 + 0] = (int16_t)ego_lane;
-  o.ego_lane[gid * 2 + 1] = (int16_t)(ego_lane >= 0 ? m.lane_index[ego_lane] : -1);
-
-  // ---- accelerometer (sensors.py:1053-1084): finite differences over a 3-deep history
-  {
-    double la[3] = {0, 0, 0}, aa[3] = {0, 0, 0}, lj[3] = {0, 0, 0}, aj[3] = {0, 0, 0};
-    if (c.sensors & SMX_SENSOR_ACCELEROMETER) {
-      int hist = k.first ? 0 : ((flags >> SMX_F_HIST_SHIFT) & 3);  // samples held before this one
-      double l0x = SF(SMX_S_LV0_LONG), l0y = SF(SMX_S_LV0_LAT), a0z = SF(SMX_S_AV0_Z);
-      double l1x = SF(SMX_S_LV1_LONG), l1y = SF(SMX_S_LV1_LAT), a1z = SF(SMX_S_AV1_Z);
-      if (hist >= 1) {
-        la[0] = (lng - l0x) / c.dt;
-        la[1] = (lat - l0y) / c.dt;
-        aa[2] = (s.r - a0z) / c.dt;
-        if (hist >= 2) {
-          lj[0] = la[0] - (l0x - l1x) / c.dt;
-          lj[1] = la[1] - (l0y - l1y) / c.dt;
-          aj[2] = aa[2] - (a0z - a1z) / c.dt;
-        }
-      }
-      SF(SMX_S_LV1_LONG) = l0x;
-      SF(SMX_S_LV1_LAT) = l0y;
-      SF(SMX_S_AV1_Z) = a0z;
-      SF(SMX_S_LV0_LONG) = lng;
-      SF(SMX_S_LV0_LAT) = lat;
-      SF(SMX_S_AV0_Z) = s.r;
-      hist = hist < 2 ? hist + 1 : 2;
-      flags = (flags & ~(3 << SMX_F_HIST_SHIFT)) | (hist << SMX_F_HIST_SHIFT);
-    }
-    for (int q = 0; q < 3; ++q) {
-      ef[SMX_EGO_LIN_ACC + q] = (float)la[q];
-      ef[SMX_EGO_ANG_ACC + q] = (float)aa[q];
-      ef[SMX_EGO_LIN_JERK + q] = (float)lj[q];
-      ef[SMX_EGO_ANG_JERK + q] = (float)aj[q];
-    }
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE)) return;
+  VehState s = load_vehicle(a, gid, total);
+  SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
+  SF(SMX_S_PREV_Y) = s.y;
+  CtrlState cs;
+  cs.lat_int = SF(SMX_S_LAT_INT);
+  cs.spd_int = SF(SMX_S_SPD_INT);
+  cs.steer = SF(SMX_S_STEER);
+  cs.throttle = SF(SMX_S_THROTTLE);
+  cs.spd_err = SF(SMX_S_SPD_ERR);
+  cs.mcl_x = SF(SMX_S_MCL_X);
+  cs.mcl_y = SF(SMX_S_MCL_Y);
+  cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
+  const int action = a.actions[gid];
+  ControlOut co;
+  if (action >= 0 && !(a.debug_skip & 1)) {
+    // Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
+    double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
+    int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
+    double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
+    double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+    PathSeeds seed = load_seeds(a, gid, total);
+    if (seed.road == -2) seed = compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true);
+    co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg, seed, knots, SMX_BLOCK);
+  } else {
+    // no action this tick: wheel torques do not persist, the steer motor target does
+    co.throttle = 0.0;
+    co.brake = 0.0;
+    co.steering = cs.steer;
   }
-
-  // ---- neighbourhood (sensors.py:241-266, smarts.py:1191-1208): every other vehicle of the
-  //      instance within `radius` (3-D distance), in slot order, first nb_max kept
-  if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !(a.debug_skip & 8)) {
-    int cnt = 0;
-    for (int j = 0; j < k.n_veh; ++j) {
-      if (j == k.slot) continue;
-      const SharedPose& p = k.env_pose[j];
-      if (!p.alive) continue;
-      if (c.nb_radius >= 0.0) {
-        double dx = p.x - px, dy = p.y - py, dz = SMX_BASE_HEIGHT - SMX_BASE_HEIGHT;
-        double d = sqrt(dx * dx + dy * dy + dz * dz);
-        if (!(d <= c.nb_radius)) continue;
-      }
-      if (cnt < c.nb_max) {
-        size_t q = gid * c.nb_max + cnt;
-        o.nb_pos[q * 3 + 0] = p.x;
-        o.nb_pos[q * 3 + 1] = p.y;
-        o.nb_pos[q * 3 + 2] = SMX_BASE_HEIGHT;
-        o.nb_box[q * 3 + 0] = (float)SMX_CHASSIS_LENGTH;
-        o.nb_box[q * 3 + 1] = (float)SMX_CHASSIS_WIDTH;
-        o.nb_box[q * 3 + 2] = (float)SMX_CHASSIS_HEIGHT;
-        o.nb_heading[q] = (float)p.heading;
-        o.nb_speed[q] = (float)p.speed;
-        // nearest_lane(nv.pose.point, radius=vehicle.length) (sensors.py:244-246)
-        int nl = (p.lane >= 0 && p.lane_dist < SMX_CHASSIS_LENGTH) ? p.lane : -1;
-        o.nb_lane_id[q] = (int16_t)nl;
-        o.nb_lane_index[q] = (int8_t)(nl >= 0 ? m.lane_index[nl] : -1);
-        o.nb_slot[q] = (int8_t)j;
-      }
-      ++cnt;
-    }
-    for (int q0 = cnt; q0 < c.nb_max; ++q0) {
-      size_t q = gid * c.nb_max + q0;
-      o.nb_pos[q * 3] = o.nb_pos[q * 3 + 1] = o.nb_pos[q * 3 + 2] = 0.0;
-      o.nb_box[q * 3] = o.nb_box[q * 3 + 1] = o.nb_box[q * 3 + 2] = 0.0f;
-      o.nb_heading[q] = 0.0f;
-      o.nb_speed[q] = 0.0f;
-      o.nb_lane_index[q] = 0;
-      o.nb_lane_id[q] = -1;
-      o.nb_slot[q] = -1;
-    }
-    o.nb_count[gid] = (uint8_t)(cnt > 255 ? 255 : cnt);
-  }
-
-  // ---- trip meter construction on a fresh vehicle (TripMeterSensor.__init__, sensors.py:885-898)
-  double dist = SF(SMX_S_DIST);
-  if (k.first) {
-    PathSeeds seed = compute_path_seeds(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
-    flags &= ~SMX_F_TRIP_HAS_WP;
-    if (seed.road >= 0 && seed.start[0] >= 0) {
-      BranchState bs;
-      bs.reset();
-      equally_spaced_path(m, seed.f, bs, seed.start[0], 1, px, py, k.knots, SMX_BLOCK, 1,
-                          [&](int, const WaypointOut& w) {
-                            SF(SMX_S_TRIP_X) = w.x;
-                            SF(SMX_S_TRIP_Y) = w.y;
-                            SF(SMX_S_TRIP_H) = w.heading;
-                            flags |= SMX_F_TRIP_HAS_WP;
-                          });
-    }
-    dist = 0.0;
-  }
-  const double last_dist = dist;
-
-  // ---- waypoint paths (sensors.py:268-275, 972-985)
-  bool have_first_wp = false;
-  double fwx = 0, fwy = 0, fwh = 0;
-  {
-    const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
-    const int lookahead = wp_on ? c.wp_lookahead : 1;
-    PathSeeds seed = wp_on ? compute_path_seeds(m, px, py, s.heading, 5.0, true)
-                           : compute_path_seeds(m, px, py, s.heading, SMX_CHASSIS_LENGTH, false);
-    // the next tick's controller asks for paths at this same pose with the agent's route
-    if (wp_on) {
-      store_seeds(a, gid, total, seed);
-    } else {
-      PathSeeds none;
-      none.road = -2;  // "not cached": the controller computes its own
-      none.f.n = 0;
-      none.n_lanes = 0;
-      none.start[0] = none.start[1] = none.start[2] = none.start[3] = -1;
-      store_seeds(a, gid, total, none);
-    }
-    int n_paths = 0;
-    const size_t per = (size_t)c.wp_paths * c.wp_len;
-    if (seed.road >= 0 && !(a.debug_skip & 16)) {
-      for (int li = 0; li < seed.n_lanes; ++li) {
-        int start = seed_start(m, seed, li, px, py);
-        if (start < 0) continue;
-        BranchState bs;
-        bs.reset();
-        do {
-          const bool keep = wp_on && n_paths < c.wp_paths;
-          const int max_emit = keep ? c.wp_len : (n_paths == 0 ? 1 : 0);
-          const size_t base = gid * per + (size_t)n_paths * c.wp_len;
-          const bool is_first_path = (n_paths == 0);
-          int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, k.knots, SMX_BLOCK, max_emit,
-                                      [&](int i, const WaypointOut& w) {
-                                        if (is_first_path && i == 0) {
-                                          have_first_wp = true;
-                                          fwx = w.x;
-                                          fwy = w.y;
-                                          fwh = w.heading;
-                                        }
-                                        if (keep) {
-                                          size_t q = base + i;
-                                          o.wp_pos[q * 3 + 0] = w.x;
-                                          o.wp_pos[q * 3 + 1] = w.y;
-                                          o.wp_pos[q * 3 + 2] = 0.0;
-                                          o.wp_heading[q] = (float)w.heading;
-                                          o.wp_lane_width[q] = (float)w.width;
-                                          o.wp_speed_limit[q] = (float)w.speed;
-                                          o.wp_lane_index[q] = (int8_t)m.lane_index[SMX_BCHK(30, w.lane, m.n_lanes)];
-                                          o.wp_lane_id[q] = (int16_t)w.lane;
-                                        }
-                                      });
-          if (keep) {
-            int kept = n < c.wp_len ? n : c.wp_len;
-            for (int i = kept; i < c.wp_len; ++i) {
-              size_t q = base + i;
-              o.wp_pos[q * 3] = o.wp_pos[q * 3 + 1] = o.wp_pos[q * 3 + 2] = 0.0;
-              o.wp_heading[q] = 0.0f;
-              o.wp_lane_width[q] = 0.0f;
-              o.wp_speed_limit[q] = 0.0f;
-              o.wp_lane_index[q] = 0;
-              o.wp_lane_id[q] = -1;
-            }
-            o.wp_count[gid * (c.wp_paths + 1) + 1 + n_paths] = (uint8_t)kept;
-          }
-          ++n_paths;
-        } while (bs.advance());
-      }
-    }
-    if (wp_on) {
-      for (int p = n_paths; p < c.wp_paths; ++p) {
-        for (int i = 0; i < c.wp_len; ++i) {
-          size_t q = gid * per + (size_t)p * c.wp_len + i;
-          o.wp_pos[q * 3] = o.wp_pos[q * 3 + 1] = o.wp_pos[q * 3 + 2] = 0.0;
-          o.wp_heading[q] = 0.0f;
-          o.wp_lane_width[q] = 0.0f;
-          o.wp_speed_limit[q] = 0.0f;
-          o.wp_lane_index[q] = 0;
-          o.wp_lane_id[q] = -1;
-        }
-        o.wp_count[gid * (c.wp_paths + 1) + 1 + p] = 0;
-      }
-      o.wp_count[gid * (c.wp_paths + 1)] = (uint8_t)(n_paths > 255 ? 255 : n_paths);
-    }
-  }
-
-  // ---- trip meter (sensors.py:900-944); reward = increment (agent_manager.py:233-234)
-  if (have_first_wp) {
-    if (!(flags & SMX_F_TRIP_HAS_WP)) {
-      SF(SMX_S_TRIP_X) = fwx;
-      SF(SMX_S_TRIP_Y) = fwy;
-      SF(SMX_S_TRIP_H) = fwh;
-      flags |= SMX_F_TRIP_HAS_WP;
-    } else {
-      double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
-      double dx = fwx - tx, dy = fwy - ty;
-      double nrm = sqrt(dx * dx + dy * dy);
-      if (nrm > 0.5) {
-        double hvx, hvy;
-        radians_to_vec(th, hvx, hvy);
-        double dot = hvx * dx + hvy * dy;
-        double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
-        dist += sgn * nrm;
-        SF(SMX_S_TRIP_X) = fwx;
-        SF(SMX_S_TRIP_Y) = fwy;
-        SF(SMX_S_TRIP_H) = fwh;
-      }
-    }
-  }
-  SF(SMX_S_DIST) = dist;
-  o.dist[gid] = dist;
-  if (k.write_reward) o.reward[gid] = dist - last_dist;
-
-  // ---- driven path (sensors.py:842-877): running length of the last window
-  bool is_not_moving = false;
-  if (a.st.driven_path != nullptr) {
-    double* ring = a.st.driven_path + gid * (size_t)SMX_DRIVEN_PATH_LEN;
-    double sum = SF(SMX_S_PATH_SUM);
-    int window_pts = (int)floor(c.not_moving_time / c.dt + 1e-9) + 1;
-    if (window_pts > SMX_DRIVEN_PATH_LEN) window_pts = SMX_DRIVEN_PATH_LEN;
-    const int K = window_pts - 1;  // segments in a full window
-    if (k.first) {
-      sum = 0.0;  // a reset records a point but no segment
-    } else {
-      double dx = k.prev_x - px, dy = k.prev_y - py;
-      double seg = sqrt(dx * dx + dy * dy);
-      int nseg = k.steps - 1;  // segments recorded so far, this one included
-      ring[(nseg - 1) % SMX_DRIVEN_PATH_LEN] = seg;
-      sum += seg;
-      if (nseg > K) sum -= ring[(nseg - 1 - K) % SMX_DRIVEN_PATH_LEN];
-    }
-    SF(SMX_S_PATH_SUM) = sum;
-    double elapsed = (double)k.env_ticks * c.dt;
-    if (!(elapsed < c.not_moving_time)) is_not_moving = sum < c.not_moving_distance;
-  }
-
-  // ---- events + done (sensors.py:443-489)
-  const bool reached_goal = false;  // EndlessGoal (plan.py:76-84)
-  const bool is_off_road = !me.on_road;  // sensors.py:498-500
-  const bool is_on_shoulder = (me.corner_mask & 15) != 15;  // sensors.py:502-509 (any corner off road)
-  const bool reached_max = c.max_episode_steps > 0 && k.steps >= c.max_episode_steps;
-  bool is_off_route, is_wrong_way;
-  {
-    // sensors.py:527-594 with no route roads (endless mission)
-    double radius = sqrt(SMX_CHASSIS_LENGTH * SMX_CHASSIS_LENGTH + SMX_CHASSIS_WIDTH * SMX_CHASSIS_WIDTH) * 0.5 + 5.0;
-    int nl = (me.lane >= 0 && me.lane_dist < radius) ? me.lane : -1;
-    if (nl < 0) {
-      is_off_route = true;
-      is_wrong_way = false;
-    } else {
-      is_off_route = false;
-      is_wrong_way = false;
-      if (!m.lane_in_junction[nl] && !(a.debug_skip & 64)) {
-        double target = lane_heading_at_point(m, nl, px, py);
-        is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
-      }
-    }
-  }
-  uint8_t* ev = o.events + gid * SMX_EV_COUNT;
-  ev[SMX_EV_COLLISIONS] = k.collided ? 1 : 0;
-  ev[SMX_EV_OFF_ROAD] = is_off_road ? 1 : 0;
-  ev[SMX_EV_OFF_ROUTE] = is_off_route ? 1 : 0;
-  ev[SMX_EV_ON_SHOULDER] = is_on_shoulder ? 1 : 0;
-  ev[SMX_EV_WRONG_WAY] = is_wrong_way ? 1 : 0;
-  ev[SMX_EV_NOT_MOVING] = is_not_moving ? 1 : 0;
-  ev[SMX_EV_REACHED_GOAL] = reached_goal ? 1 : 0;
-  ev[SMX_EV_REACHED_MAX_EPISODE_STEPS] = reached_max ? 1 : 0;
-  ev[SMX_EV_AGENTS_ALIVE_DONE] = 0;
-  const uint32_t dc = c.done_criteria;
-  return (is_off_road && (dc & SMX_DONE_OFF_ROAD)) || reached_goal || reached_max ||
-         (is_on_shoulder && (dc & SMX_DONE_ON_SHOULDER)) || (k.collided && (dc & SMX_DONE_COLLISION)) ||
-         (is_not_moving && (dc & SMX_DONE_NOT_MOVING)) || (is_off_route && (dc & SMX_DONE_OFF_ROUTE)) ||
-         (is_wrong_way && (dc & SMX_DONE_WRONG_WAY));
+  vehicle_step(s, co, c.dt);
+  SF(SMX_S_X) = s.x;
+  SF(SMX_S_Y) = s.y;
+  SF(SMX_S_HEADING) = s.heading;
+  SF(SMX_S_U) = s.u;
+  SF(SMX_S_V) = s.v;
+  SF(SMX_S_R) = s.r;
+  SF(SMX_S_DELTA) = s.delta;
+  SF(SMX_S_LAT_INT) = cs.lat_int;
+  SF(SMX_S_SPD_INT) = cs.spd_int;
+  SF(SMX_S_STEER) = cs.steer;
+  SF(SMX_S_THROTTLE) = cs.throttle;
+  SF(SMX_S_SPD_ERR) = cs.spd_err;
+  SF(SMX_S_MCL_X) = cs.mcl_x;
+  SF(SMX_S_MCL_Y) = cs.mcl_y;
+  a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
 }
 
-// Pose pass: publish this vehicle's pose and its road facts to the env-mates.  One sweep of the
-// segment grid answers the tick's nearest_lane queries at the vehicle centre (ego lane, neighbour
-// lanes, off-route check: all "nearest lane if closer than r") and road_with_point at the centre
-// and at the four bounding-box corners (Vehicle.bounding_box, vehicle.py:315-332, through
-// rotate_around_point, math.py:436-444).
-#define SMX_POSE_SCAN_RADIUS 10.0
-__device__ __forceinline__ void publish_pose(const MapDev& m, SharedPose& p, const VehState& s, bool alive, int dbg) {
-  p.x = s.x;
-  p.y = s.y;
-  p.heading = wrap_heading(s.heading);
-  p.speed = vehicle_speed(s);
-  p.alive = alive ? 1 : 0;
-  p.lane = -1;
-  p.lane_dist = SMX_INF;
-  p.on_road = 0;
-  p.corner_mask = 0;
-  if (alive && !(dbg & 2)) {
+// =================================================================================
+// k_scan: map sweeps at the vehicle's pose, SMX_TEAM lanes per vehicle.
+//   facts: nearest lane + distance (nearest_lane with any radius up to 10 m is "that lane if
+//          closer than r": ego lane sensors.py:277, neighbour lanes :244, off-route :552),
+//          road_with_point at the centre (:498-500) and at the four bounding-box corners
+//          (:502-509; Vehicle.bounding_box vehicle.py:315-332, rotate_around_point math.py:436-444)
+//   seeds: start road / route filter / start lanepoints of waypoint_paths(pose, route)
+//          (sumo_road_network.py:815-882), used by k_waypoints now and by k_control next tick
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
+  const int rank = team_rank();
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE)) return;
+  if (a.first_only && !(flags & SMX_F_FIRST)) return;
+  const VehState s = load_vehicle(a, gid, total);
+  int32_t* fi = a.st.facts_i32;
+  // ---- road facts
+  {
     const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
     const double cys[4] = {0.5, 0.5, -0.5, -0.5};
     double cx[4], cy[4];
@@ -653,29 +377,330 @@ __device__ __forceinline__ void publish_pose(const MapDev& m, SharedPose& p, con
       cx[q] = s.x + ch * (qx - s.x) + sh * (qy - s.y);
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
-    RoadFacts h = road_facts_scan(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width),
-                                  (dbg & 32) ? 0 : 4, cx, cy);
-    p.lane = h.lane;
-    p.lane_dist = h.dist;
-    p.on_road = h.on_road ? 1 : 0;
-    p.corner_mask = (dbg & 32) ? 15 : h.corner_mask;
+    RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), 4, cx, cy);
+    if (rank == 0) {
+      fi[(size_t)SMX_FI_LANE * total + gid] = h.lane;
+      fi[(size_t)SMX_FI_FLAGS * total + gid] =
+          (h.on_road ? SMX_FACT_ON_ROAD : 0) | ((h.corner_mask & 15) << SMX_FACT_CORNER_SHIFT);
+      a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid] = h.dist;
+    }
+  }
+  // ---- path seeds
+  Top10 t;
+  team_nearest10(m, s.x, s.y, t);
+  const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
+  // what the controller (and the waypoints sensor) ask: paths at this pose with the agent's route
+  const PathSeeds seed = team_compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true, t);
+  // without the waypoints sensor the observation still takes the first waypoint of
+  // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
+  // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
+  int obs_start = -1, trip_start = -1;
+  if (!wp_on || (flags & SMX_F_FIRST)) {
+    const PathSeeds ts = team_compute_path_seeds(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t);
+    trip_start = (ts.road >= 0) ? ts.start[0] : -1;
+    obs_start = trip_start;
+  }
+  if (rank == 0) {
+    store_seeds(a, gid, total, seed);
+    fi[(size_t)SMX_FI_TRIP_START * total + gid] = (flags & SMX_F_FIRST) ? trip_start : -1;
+    fi[(size_t)SMX_FI_OBS_START * total + gid] = obs_start;
   }
 }
 
-// ---------------------------------------------------------------------------------
-// the tick kernel.  mode 0: one SMARTS step for every env.  mode 1: reset the masked envs.
-// ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a, const int mode) {
-  __shared__ SharedPose pose[SMX_BLOCK];
-  __shared__ int env_new_done[SMX_BLOCK];
-  __shared__ int env_need_reset[SMX_BLOCK];
-  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
-  int* knots = knot_scratch + threadIdx.x;
+// =================================================================================
+// k_waypoints: waypoint paths (sensors.py:268-275, 972-985) + trip meter (sensors.py:880-947).
+// SMX_WP_LANES lanes per vehicle: lane p synthesises kept path p (p + 4, ...); results are staged
+// in LDS in the exact byte layout of the dense outputs and leave as whole 16-byte pieces.
+// =================================================================================
+struct WpStageLayout {
+  int per_vehicle;  // bytes of staged waypoint data per vehicle
+  int off_pos, off_heading, off_width, off_speed, off_lidx, off_lid;
+};
 
+__device__ __forceinline__ WpStageLayout wp_layout(int P, int W) {
+  WpStageLayout L;
+  const int n = P * W;
+  L.off_pos = 0;
+  L.off_heading = n * 24;
+  L.off_width = L.off_heading + n * 4;
+  L.off_speed = L.off_width + n * 4;
+  L.off_lid = L.off_speed + n * 4;
+  L.off_lidx = L.off_lid + n * 2;
+  L.per_vehicle = (L.off_lidx + n + 15) & ~15;
+  return L;
+}
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
+  extern __shared__ __align__(16) unsigned char stage[];
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  __shared__ int veh_live[SMX_BLOCK / SMX_WP_LANES];
+  int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
+  const smx_outputs& o = a.out;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int VPB = SMX_BLOCK / SMX_WP_LANES;  // vehicles per block
+  const int vloc = threadIdx.x / SMX_WP_LANES;
+  const int p0 = threadIdx.x % SMX_WP_LANES;
+  const size_t gid = (size_t)blockIdx.x * VPB + vloc;
+  const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
+  const int P = c.wp_paths, W = c.wp_len;
+  const WpStageLayout L = wp_layout(P, W);
+  unsigned char* mine = stage + (size_t)vloc * L.per_vehicle;
+
+  int flags = 0;
+  bool live = false;
+  if (gid < total) {
+    flags = a.st.flags[gid];
+    live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
+  }
+  if (p0 == 0) veh_live[vloc] = live ? 1 : 0;
+  // zero the staging area (padding rows / unused paths are zeros, format_obs.py:589-596)
+  if (wp_on) {
+    const int words = (VPB * L.per_vehicle) / 4;
+    for (int k = threadIdx.x; k < words; k += SMX_BLOCK) reinterpret_cast<int*>(stage)[k] = 0;
+  }
+  __syncthreads();
+
+  bool have_first_wp = false;
+  double fwx = 0, fwy = 0, fwh = 0;
+  int n_paths_total = 0;
+  if (live) {
+    const VehState s = load_vehicle(a, gid, total);
+    const double px = s.x, py = s.y;
+    const PathSeeds seed = load_seeds(a, gid, total);
+    const int lookahead = wp_on ? c.wp_lookahead : 1;
+    if (wp_on) {
+      // -1 lane ids for the rows that stay empty
+      short* lid = reinterpret_cast<short*>(mine + L.off_lid);
+      for (int k = p0; k < P * W; k += SMX_WP_LANES) lid[k] = -1;
+    }
+    if (!wp_on) {
+      // only the first waypoint of the first path is needed (trip meter)
+      const int os = a.st.facts_i32[(size_t)SMX_FI_OBS_START * total + gid];
+      if (p0 == 0 && os >= 0) {
+        BranchState bs;
+        bs.reset();
+        RouteFilter nof;
+        nof.n = 0;
+        equally_spaced_path(m, nof, bs, os, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+          have_first_wp = true;
+          fwx = w.x;
+          fwy = w.y;
+          fwh = w.heading;
+        });
+      }
+    } else if (seed.road >= 0 && !(a.debug_skip & 16)) {
+      // enumerate the paths in the reference's order (lanes by index, branches depth-first); lane p0
+      // synthesises paths p0, p0 + 4, ...; lane 0 also counts them all
+      int idx = 0;
+      for (int li = 0; li < seed.n_lanes; ++li) {
+        int start = seed_start(m, seed, li, px, py);
+        if (start < 0) continue;
+        BranchState bs;
+        bs.reset();
+        do {
+          const bool kept = wp_on && idx < P && (idx % SMX_WP_LANES) == p0;
+          const bool first_path = (idx == 0 && p0 == 0);
+          if (kept || first_path) {
+            const int base = idx * W;
+            const int max_emit = kept ? W : 1;
+            int n = equally_spaced_path(
+                m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, max_emit, [&](int i, const WaypointOut& w) {
+                  if (first_path && i == 0) {
+                    have_first_wp = true;
+                    fwx = w.x;
+                    fwy = w.y;
+                    fwh = w.heading;
+                  }
+                  if (kept) {
+                    const int q = base + i;
+                    double* pos = reinterpret_cast<double*>(mine + L.off_pos) + (size_t)q * 3;
+                    pos[0] = w.x;
+                    pos[1] = w.y;
+                    pos[2] = 0.0;
+                    reinterpret_cast<float*>(mine + L.off_heading)[q] = (float)w.heading;
+                    reinterpret_cast<float*>(mine + L.off_width)[q] = (float)w.width;
+                    reinterpret_cast<float*>(mine + L.off_speed)[q] = (float)w.speed;
+                    reinterpret_cast<short*>(mine + L.off_lid)[q] = (short)w.lane;
+                    reinterpret_cast<signed char*>(mine + L.off_lidx)[q] = (signed char)m.lane_index[w.lane];
+                  }
+                });
+            if (kept) o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+          } else if (p0 == 0 || idx < P) {
+            // walk only: discovers the branchings (and, on lane 0, counts the path)
+            equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, 0,
+                                [&](int, const WaypointOut&) {});
+          }
+          ++idx;
+        } while (bs.advance() && (p0 == 0 || idx < P));
+      }
+      n_paths_total = idx;
+    }
+    if (p0 == 0) {
+      if (wp_on) {
+        o.wp_count[gid * (P + 1)] = (uint8_t)(n_paths_total > 255 ? 255 : n_paths_total);
+        for (int p = n_paths_total; p < P; ++p) o.wp_count[gid * (P + 1) + 1 + p] = 0;
+      }
+      // ---- trip meter (sensors.py:880-947); reward = increment (agent_manager.py:233-234)
+      double dist = SF(SMX_S_DIST);
+      if (flags & SMX_F_FIRST) {
+        // TripMeterSensor.__init__: first waypoint of the lowest lane, lookahead-1 path, no route
+        flags &= ~SMX_F_TRIP_HAS_WP;
+        const int ts = a.st.facts_i32[(size_t)SMX_FI_TRIP_START * total + gid];
+        if (ts >= 0) {
+          BranchState bs;
+          bs.reset();
+          RouteFilter nof;
+          nof.n = 0;
+          equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+            SF(SMX_S_TRIP_X) = w.x;
+            SF(SMX_S_TRIP_Y) = w.y;
+            SF(SMX_S_TRIP_H) = w.heading;
+            flags |= SMX_F_TRIP_HAS_WP;
+          });
+        }
+        dist = 0.0;
+      }
+      const double last_dist = dist;
+      if (have_first_wp) {
+        if (!(flags & SMX_F_TRIP_HAS_WP)) {
+          SF(SMX_S_TRIP_X) = fwx;
+          SF(SMX_S_TRIP_Y) = fwy;
+          SF(SMX_S_TRIP_H) = fwh;
+          flags |= SMX_F_TRIP_HAS_WP;
+        } else {
+          double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
+          double dx = fwx - tx, dy = fwy - ty;
+          double nrm = sqrt(dx * dx + dy * dy);
+          if (nrm > 0.5) {
+            double hvx, hvy;
+            radians_to_vec(th, hvx, hvy);
+            double dot = hvx * dx + hvy * dy;
+            double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
+            dist += sgn * nrm;
+            SF(SMX_S_TRIP_X) = fwx;
+            SF(SMX_S_TRIP_Y) = fwy;
+            SF(SMX_S_TRIP_H) = fwh;
+          }
+        }
+      }
+      SF(SMX_S_DIST) = dist;
+      o.dist[gid] = dist;
+      if (!a.keep_reward_done) o.reward[gid] = dist - last_dist;
+      // only the trip-meter bit may change here; k_observe owns the other flag bits
+      a.st.flags[gid] = (a.st.flags[gid] & ~SMX_F_TRIP_HAS_WP) | (flags & SMX_F_TRIP_HAS_WP);
+    }
+  }
+  __syncthreads();
+  // ---- copy-out: each array's slice of a vehicle is contiguous in global memory, and so are
+  // consecutive vehicles, so the block's staged bytes leave as runs of 16-byte pieces
+  if (wp_on) {
+    const size_t v0 = (size_t)blockIdx.x * VPB;
+    const int n = P * W;
+    struct Seg {
+      unsigned char* dst;
+      int off, bytes;
+    };
+    const Seg segs[6] = {
+        {reinterpret_cast<unsigned char*>(o.wp_pos), L.off_pos, n * 24},
+        {reinterpret_cast<unsigned char*>(o.wp_heading), L.off_heading, n * 4},
+        {reinterpret_cast<unsigned char*>(o.wp_lane_width), L.off_width, n * 4},
+        {reinterpret_cast<unsigned char*>(o.wp_speed_limit), L.off_speed, n * 4},
+        {reinterpret_cast<unsigned char*>(o.wp_lane_id), L.off_lid, n * 2},
+        {reinterpret_cast<unsigned char*>(o.wp_lane_index), L.off_lidx, n},
+    };
+#pragma unroll
+    for (int sgi = 0; sgi < 6; ++sgi) {
+      const int bytes = segs[sgi].bytes;
+      if ((bytes & 15) == 0) {
+        const int pieces = bytes / 16;
+        for (int k = threadIdx.x; k < VPB * pieces; k += SMX_BLOCK) {
+          const int v = k / pieces, w = k - v * pieces;
+          if (v0 + v >= total || !veh_live[v]) continue;
+          const int4 val = *reinterpret_cast<const int4*>(stage + (size_t)v * L.per_vehicle + segs[sgi].off + w * 16);
+          *reinterpret_cast<int4*>(segs[sgi].dst + (v0 + v) * (size_t)bytes + (size_t)w * 16) = val;
+        }
+      } else {
+        const int pieces = bytes / 4;  // every slice is a multiple of 4 bytes for even P * W
+        const int tail = bytes & 3;
+        for (int k = threadIdx.x; k < VPB * pieces; k += SMX_BLOCK) {
+          const int v = k / pieces, w = k - v * pieces;
+          if (v0 + v >= total || !veh_live[v]) continue;
+          const int val = *reinterpret_cast<const int*>(stage + (size_t)v * L.per_vehicle + segs[sgi].off + w * 4);
+          *reinterpret_cast<int*>(segs[sgi].dst + (v0 + v) * (size_t)bytes + (size_t)w * 4) = val;
+        }
+        if (tail) {
+          for (int k = threadIdx.x; k < VPB * tail; k += SMX_BLOCK) {
+            const int v = k / tail, w = pieces * 4 + (k - v * tail);
+            if (v0 + v >= total || !veh_live[v]) continue;
+            segs[sgi].dst[(v0 + v) * (size_t)bytes + w] = stage[(size_t)v * L.per_vehicle + segs[sgi].off + w];
+          }
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================
+// k_observe: the rest of Sensors.observe (sensors.py:238-396) and the events / done logic
+// (sensors.py:443-594), one thread per vehicle, whole envs per workgroup (env-mates' poses in LDS)
+// =================================================================================
+struct __align__(16) SharedPose {
+  double x, y, heading, speed;
+  double lane_dist;
+  int lane;
+  int alive;
+};
+
+__device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid) {
+  const smx_config& c = a.cfg;
+  const smx_outputs& o = a.out;
+  for (int k = 0; k < 3; ++k) o.ego_pos[gid * 3 + k] = 0.0;
+  for (int k = 0; k < SMX_EGO_F32_COUNT; ++k) o.ego_f32[gid * SMX_EGO_F32_COUNT + k] = 0.0f;
+  o.ego_lane[gid * 2] = -1;
+  o.ego_lane[gid * 2 + 1] = -1;
+  for (int k = 0; k < SMX_EV_COUNT; ++k) o.events[gid * SMX_EV_COUNT + k] = 0;
+  o.reward[gid] = 0.0;
+  o.dist[gid] = 0.0;
+  if (c.sensors & SMX_SENSOR_WAYPOINTS) {
+    size_t per = (size_t)c.wp_paths * c.wp_len;
+    for (size_t k = 0; k < per; ++k) {
+      size_t q = gid * per + k;
+      o.wp_pos[q * 3] = 0.0;
+      o.wp_pos[q * 3 + 1] = 0.0;
+      o.wp_pos[q * 3 + 2] = 0.0;
+      o.wp_heading[q] = 0.0f;
+      o.wp_lane_width[q] = 0.0f;
+      o.wp_speed_limit[q] = 0.0f;
+      o.wp_lane_index[q] = 0;
+      o.wp_lane_id[q] = -1;
+    }
+    for (int k = 0; k <= c.wp_paths; ++k) o.wp_count[gid * (c.wp_paths + 1) + k] = 0;
+  }
+  if (c.sensors & SMX_SENSOR_NEIGHBORS) {
+    for (int k = 0; k < c.nb_max; ++k) {
+      size_t q = gid * c.nb_max + k;
+      o.nb_pos[q * 3] = o.nb_pos[q * 3 + 1] = o.nb_pos[q * 3 + 2] = 0.0;
+      o.nb_box[q * 3] = o.nb_box[q * 3 + 1] = o.nb_box[q * 3 + 2] = 0.0f;
+      o.nb_heading[q] = 0.0f;
+      o.nb_speed[q] = 0.0f;
+      o.nb_lane_index[q] = 0;
+      o.nb_lane_id[q] = -1;
+      o.nb_slot[q] = -1;
+    }
+    o.nb_count[gid] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
+  __shared__ SharedPose pose[SMX_BLOCK];
+  __shared__ int env_new_done[SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const smx_outputs& o = a.out;
   const int n_veh = c.num_vehicles;
-  const int epb = a.envs_per_block;
+  const int epb = SMX_BLOCK / n_veh;
   const int local = threadIdx.x;
   const int env_local = local / n_veh;
   const int slot = local - env_local * n_veh;
@@ -686,197 +711,310 @@ __global__ void __launch_bounds__(SMX_BLOCK) smx_tick_kernel(const KernelArgs a,
   const SharedPose* env_pose = pose + env_local * n_veh;
 
   env_new_done[local] = 0;
-  env_need_reset[local] = 0;
-
   VehState s = {0, 0, 0, 0, 0, 0, 0};
-  int flags = 0, steps = 0, env_ticks = 0;
+  int flags = 0;
   bool alive = false;
+  int my_lane = -1, my_facts = 0;
+  double my_lane_dist = SMX_INF;
   if (valid) {
     flags = a.st.flags[gid];
-    steps = a.st.steps[gid];
-    env_ticks = a.st.env_ticks[env];
     alive = (flags & SMX_F_ALIVE) != 0;
-    s.x = SF(SMX_S_X);
-    s.y = SF(SMX_S_Y);
-    s.heading = SF(SMX_S_HEADING);
-    s.u = SF(SMX_S_U);
-    s.v = SF(SMX_S_V);
-    s.r = SF(SMX_S_R);
-    s.delta = SF(SMX_S_DELTA);
+    s = load_vehicle(a, gid, total);
+    if (alive) {
+      my_lane = a.st.facts_i32[(size_t)SMX_FI_LANE * total + gid];
+      my_facts = a.st.facts_i32[(size_t)SMX_FI_FLAGS * total + gid];
+      my_lane_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
+    }
+  }
+  const double speed = vehicle_speed(s);
+  {
+    SharedPose& p = pose[local];
+    p.x = s.x;
+    p.y = s.y;
+    p.heading = wrap_heading(s.heading);
+    p.speed = speed;
+    p.lane = my_lane;
+    p.lane_dist = my_lane_dist;
+    p.alive = (valid && alive) ? 1 : 0;
   }
   __syncthreads();
 
-  if (mode == 0) {
-    // ================= A + B: controllers, physics =================
-    const double prev_x = s.x, prev_y = s.y;
-    if (valid && alive) {
-      CtrlState cs;
-      cs.lat_int = SF(SMX_S_LAT_INT);
-      cs.spd_int = SF(SMX_S_SPD_INT);
-      cs.steer = SF(SMX_S_STEER);
-      cs.throttle = SF(SMX_S_THROTTLE);
-      cs.spd_err = SF(SMX_S_SPD_ERR);
-      cs.mcl_x = SF(SMX_S_MCL_X);
-      cs.mcl_y = SF(SMX_S_MCL_Y);
-      cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
-      const int action = a.actions[gid];
-      ControlOut co;
-      if (action >= 0 && !(a.debug_skip & 1)) {
-        // Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
-        double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
-        int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
-        double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
-        double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
-        PathSeeds seed = load_seeds(a, gid, total);
-        if (seed.road == -2) seed = compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true);
-        co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg, seed, knots, SMX_BLOCK);
-      } else {
-        // no action this tick: wheel torques do not persist, the steer motor target does
-        co.throttle = 0.0;
-        co.brake = 0.0;
-        co.steering = cs.steer;
-      }
-      vehicle_step(s, co, c.dt);
-      SF(SMX_S_LAT_INT) = cs.lat_int;
-      SF(SMX_S_SPD_INT) = cs.spd_int;
-      SF(SMX_S_STEER) = cs.steer;
-      SF(SMX_S_THROTTLE) = cs.throttle;
-      SF(SMX_S_SPD_ERR) = cs.spd_err;
-      SF(SMX_S_MCL_X) = cs.mcl_x;
-      SF(SMX_S_MCL_Y) = cs.mcl_y;
-      flags = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
-    }
-    if (valid) ++env_ticks;  // smarts.py:261-262 (every thread of the env keeps the same copy)
-    publish_pose(m, pose[local], s, valid && alive, a.debug_skip);
-    __syncthreads();
+  const bool first = (flags & SMX_F_FIRST) != 0;
+  const bool mine = valid && alive && (!a.first_only || first);
+  bool done = false;
+  if (mine) {
+    const double px = s.x, py = s.y;
+    int steps = a.st.steps[gid];
+    const int env_ticks = first ? a.st.env_ticks[env] : a.st.env_ticks[env] + 1;  // smarts.py:261-262
+    if (!first) ++steps;  // SensorState.step (agent_manager.py:250-258); a new vehicle starts at 1
 
-    // ================= C: collisions =================
+    // ---- collisions (smarts.py:1270-1291): a new vehicle has not been through a physics step
     bool collided = false;
-    if (valid && alive && !(a.debug_skip & 4)) {
+    if (!first && !(a.debug_skip & 4)) {
       for (int j = 0; j < n_veh; ++j) {
         if (j == slot) continue;
-        const SharedPose& p = env_pose[j];
-        if (!p.alive) continue;
-        if (boxes_within(s.x, s.y, wrap_heading(s.heading), p.x, p.y, p.heading, SMX_CHASSIS_LENGTH,
-                         SMX_CHASSIS_WIDTH, SMX_COLLISION_LEEWAY))
+        const SharedPose& q = env_pose[j];
+        if (!q.alive) continue;
+        if (boxes_within(px, py, wrap_heading(s.heading), q.x, q.y, q.heading, SMX_CHASSIS_LENGTH, SMX_CHASSIS_WIDTH,
+                         SMX_COLLISION_LEEWAY))
           collided = true;
       }
     }
 
-    // ================= D: sensors =================
-    bool done = false;
-    if (valid) {
-      if (alive) {
-        ++steps;
-        ObserveCtx k;
-        k.gid = gid;
-        k.total = total;
-        k.slot = slot;
-        k.n_veh = n_veh;
-        k.env_pose = env_pose;
-        k.collided = collided;
-        k.steps = steps;
-        k.env_ticks = env_ticks;
-        k.prev_x = prev_x;
-        k.prev_y = prev_y;
-        k.first = false;
-        k.write_reward = true;
-        k.knots = knots;
-        done = observe_vehicle(a, k, s, flags);
-        // ================= E: teardown (smarts.py:314, 329-363) =================
-        if (done) {
-          flags &= ~SMX_F_ALIVE;
-          atomicAdd(&env_new_done[env_local], 1);
+    double lng, lat;
+    long_lat_speed(s, lng, lat);
+    // ---- ego lane (sensors.py:277-285): nearest lane within max(10, 2 * default lane width)
+    const int ego_lane = (my_lane >= 0 && my_lane_dist < fmax(10.0, 2.0 * m.default_lane_width)) ? my_lane : -1;
+    // ---- ego vehicle state (sensors.py:314-329; read-back of chassis.py:493-566)
+    o.ego_pos[gid * 3 + 0] = px;
+    o.ego_pos[gid * 3 + 1] = py;
+    o.ego_pos[gid * 3 + 2] = SMX_BASE_HEIGHT;
+    float* ef = o.ego_f32 + gid * SMX_EGO_F32_COUNT;
+    ef[SMX_EGO_HEADING] = (float)wrap_heading(s.heading);
+    ef[SMX_EGO_SPEED] = (float)speed;
+    ef[SMX_EGO_STEERING] = (float)(-s.delta);
+    ef[SMX_EGO_YAW_RATE] = (float)vec_to_radians(0.0, 0.0);  // chassis.py:552-556 on a planar body
+    ef[SMX_EGO_LIN_VEL + 0] = (float)lng;
+    ef[SMX_EGO_LIN_VEL + 1] = (float)lat;
+    ef[SMX_EGO_LIN_VEL + 2] = 0.0f;
+    ef[SMX_EGO_ANG_VEL + 0] = 0.0f;
+    ef[SMX_EGO_ANG_VEL + 1] = 0.0f;
+    ef[SMX_EGO_ANG_VEL + 2] = (float)s.r;
+    ef[SMX_EGO_BOX + 0] = (float)SMX_CHASSIS_LENGTH;
+    ef[SMX_EGO_BOX + 1] = (float)SMX_CHASSIS_WIDTH;
+    ef[SMX_EGO_BOX + 2] = (float)SMX_CHASSIS_HEIGHT;
+    o.ego_lane[gid * 2 + 0] = (int16_t)ego_lane;
+    o.ego_lane[gid * 2 + 1] = (int16_t)(ego_lane >= 0 ? m.lane_index[ego_lane] : -1);
+
+    // ---- accelerometer (sensors.py:1053-1084): finite differences over a 3-deep history
+    {
+      double la[3] = {0, 0, 0}, aa[3] = {0, 0, 0}, lj[3] = {0, 0, 0}, aj[3] = {0, 0, 0};
+      if (c.sensors & SMX_SENSOR_ACCELEROMETER) {
+        int hist = first ? 0 : ((flags >> SMX_F_HIST_SHIFT) & 3);  // samples held before this one
+        double l0x = SF(SMX_S_LV0_LONG), l0y = SF(SMX_S_LV0_LAT), a0z = SF(SMX_S_AV0_Z);
+        double l1x = SF(SMX_S_LV1_LONG), l1y = SF(SMX_S_LV1_LAT), a1z = SF(SMX_S_AV1_Z);
+        if (hist >= 1) {
+          la[0] = (lng - l0x) / c.dt;
+          la[1] = (lat - l0y) / c.dt;
+          aa[2] = (s.r - a0z) / c.dt;
+          if (hist >= 2) {
+            lj[0] = la[0] - (l0x - l1x) / c.dt;
+            lj[1] = la[1] - (l0y - l1y) / c.dt;
+            aj[2] = aa[2] - (a0z - a1z) / c.dt;
+          }
         }
-        SF(SMX_S_X) = s.x;
-        SF(SMX_S_Y) = s.y;
-        SF(SMX_S_HEADING) = s.heading;
-        SF(SMX_S_U) = s.u;
-        SF(SMX_S_V) = s.v;
-        SF(SMX_S_R) = s.r;
-        SF(SMX_S_DELTA) = s.delta;
-        a.st.steps[gid] = steps;
-        a.st.flags[gid] = flags;
-        a.out.done[gid] = done ? 1 : 0;
-        a.out.active[gid] = done ? 0 : 1;
-      } else {
-        zero_outputs(a, gid);
-        a.out.dist[gid] = 0.0;
-        a.out.done[gid] = 0;
-        a.out.active[gid] = 0;
+        SF(SMX_S_LV1_LONG) = l0x;
+        SF(SMX_S_LV1_LAT) = l0y;
+        SF(SMX_S_AV1_Z) = a0z;
+        SF(SMX_S_LV0_LONG) = lng;
+        SF(SMX_S_LV0_LAT) = lat;
+        SF(SMX_S_AV0_Z) = s.r;
+        hist = hist < 2 ? hist + 1 : 2;
+        flags = (flags & ~(3 << SMX_F_HIST_SHIFT)) | (hist << SMX_F_HIST_SHIFT);
+      }
+      for (int q = 0; q < 3; ++q) {
+        ef[SMX_EGO_LIN_ACC + q] = (float)la[q];
+        ef[SMX_EGO_ANG_ACC + q] = (float)aa[q];
+        ef[SMX_EGO_LIN_JERK + q] = (float)lj[q];
+        ef[SMX_EGO_ANG_JERK + q] = (float)aj[q];
       }
     }
-    __syncthreads();
-    if (valid && slot == 0) {
-      int dc = a.st.env_done_count[env] + env_new_done[env_local];
-      a.st.env_done_count[env] = dc;
-      a.st.env_ticks[env] = env_ticks;
-      bool all_done = dc >= n_veh;  // hiway_env.py:258-261
-      a.out.env_done[env] = all_done ? 1 : 0;
-      env_need_reset[env_local] = (all_done && c.auto_reset) ? 1 : 0;
-    }
-  } else {
-    if (valid && slot == 0) env_need_reset[env_local] = (a.env_mask == nullptr || a.env_mask[env]) ? 1 : 0;
-  }
-  __syncthreads();
 
-  // ================= reset (SMARTS.reset, smarts.py:365-460; ParallelEnv auto-reset) =================
-  const bool do_reset = valid && env_need_reset[env_local] != 0;
-  const int episode = do_reset ? a.st.env_episode[env] + 1 : 0;  // every reset starts the next spawn row
-  if (do_reset) {
-    const int row = a.sp.episodes > 0 ? (((episode % a.sp.episodes) + a.sp.episodes) % a.sp.episodes) : 0;
-    const double* sp = a.sp.pose + ((size_t)row * total + gid) * 4;
-    s.x = sp[0];
-    s.y = sp[1];
-    s.heading = wrap_heading(sp[2]);
-    s.u = sp[3];  // AckermannChassis._initialize_speed (chassis.py:668-671)
-    s.v = 0.0;
-    s.r = 0.0;
-    s.delta = 0.0;
-    flags = SMX_F_ALIVE;
-    steps = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
-    env_ticks = c.reset_elapsed_steps;
-    for (int f = SMX_S_LAT_INT; f < SMX_S_COUNT; ++f) SF(f) = 0.0;
-  }
-  publish_pose(m, pose[local], s, do_reset, a.debug_skip);
-  __syncthreads();
-  if (do_reset) {
-    ObserveCtx k;
-    k.gid = gid;
-    k.total = total;
-    k.slot = slot;
-    k.n_veh = n_veh;
-    k.env_pose = env_pose;
-    k.collided = false;
-    k.steps = steps;
-    k.env_ticks = env_ticks;
-    k.prev_x = s.x;
-    k.prev_y = s.y;
-    k.first = true;
-    k.write_reward = (mode != 0);
-    k.knots = knots;
-    observe_vehicle(a, k, s, flags);
-    SF(SMX_S_X) = s.x;
-    SF(SMX_S_Y) = s.y;
-    SF(SMX_S_HEADING) = s.heading;
-    SF(SMX_S_U) = s.u;
-    SF(SMX_S_V) = s.v;
-    SF(SMX_S_R) = s.r;
-    SF(SMX_S_DELTA) = s.delta;
+    // ---- neighbourhood (sensors.py:241-266, smarts.py:1191-1208): every other vehicle of the
+    //      instance within `radius` (3-D distance), in slot order, first nb_max kept
+    if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !(a.debug_skip & 8)) {
+      int cnt = 0;
+      for (int j = 0; j < n_veh; ++j) {
+        if (j == slot) continue;
+        const SharedPose& q = env_pose[j];
+        if (!q.alive) continue;
+        if (c.nb_radius >= 0.0) {
+          double dx = q.x - px, dy = q.y - py, dz = SMX_BASE_HEIGHT - SMX_BASE_HEIGHT;
+          double d = sqrt(dx * dx + dy * dy + dz * dz);
+          if (!(d <= c.nb_radius)) continue;
+        }
+        if (cnt < c.nb_max) {
+          size_t w = gid * c.nb_max + cnt;
+          o.nb_pos[w * 3 + 0] = q.x;
+          o.nb_pos[w * 3 + 1] = q.y;
+          o.nb_pos[w * 3 + 2] = SMX_BASE_HEIGHT;
+          o.nb_box[w * 3 + 0] = (float)SMX_CHASSIS_LENGTH;
+          o.nb_box[w * 3 + 1] = (float)SMX_CHASSIS_WIDTH;
+          o.nb_box[w * 3 + 2] = (float)SMX_CHASSIS_HEIGHT;
+          o.nb_heading[w] = (float)q.heading;
+          o.nb_speed[w] = (float)q.speed;
+          // nearest_lane(nv.pose.point, radius=vehicle.length) (sensors.py:244-246)
+          int nl = (q.lane >= 0 && q.lane_dist < SMX_CHASSIS_LENGTH) ? q.lane : -1;
+          o.nb_lane_id[w] = (int16_t)nl;
+          o.nb_lane_index[w] = (int8_t)(nl >= 0 ? m.lane_index[nl] : -1);
+          o.nb_slot[w] = (int8_t)j;
+        }
+        ++cnt;
+      }
+      for (int q0 = cnt; q0 < c.nb_max; ++q0) {
+        size_t w = gid * c.nb_max + q0;
+        o.nb_pos[w * 3] = o.nb_pos[w * 3 + 1] = o.nb_pos[w * 3 + 2] = 0.0;
+        o.nb_box[w * 3] = o.nb_box[w * 3 + 1] = o.nb_box[w * 3 + 2] = 0.0f;
+        o.nb_heading[w] = 0.0f;
+        o.nb_speed[w] = 0.0f;
+        o.nb_lane_index[w] = 0;
+        o.nb_lane_id[w] = -1;
+        o.nb_slot[w] = -1;
+      }
+      o.nb_count[gid] = (uint8_t)(cnt > 255 ? 255 : cnt);
+    }
+
+    // ---- driven path (sensors.py:842-877): running length of the last window
+    bool is_not_moving = false;
+    if (a.st.driven_path != nullptr) {
+      double* ring = a.st.driven_path + gid * (size_t)SMX_DRIVEN_PATH_LEN;
+      double sum = SF(SMX_S_PATH_SUM);
+      int window_pts = (int)floor(c.not_moving_time / c.dt + 1e-9) + 1;
+      if (window_pts > SMX_DRIVEN_PATH_LEN) window_pts = SMX_DRIVEN_PATH_LEN;
+      const int K = window_pts - 1;  // segments in a full window
+      if (first) {
+        sum = 0.0;  // a reset records a point but no segment
+      } else {
+        double dx = SF(SMX_S_PREV_X) - px, dy = SF(SMX_S_PREV_Y) - py;
+        double seg = sqrt(dx * dx + dy * dy);
+        int nseg = steps - 1;  // segments recorded so far, this one included
+        ring[(nseg - 1) % SMX_DRIVEN_PATH_LEN] = seg;
+        sum += seg;
+        if (nseg > K) sum -= ring[(nseg - 1 - K) % SMX_DRIVEN_PATH_LEN];
+      }
+      SF(SMX_S_PATH_SUM) = sum;
+      double elapsed = (double)env_ticks * c.dt;
+      if (!(elapsed < c.not_moving_time)) is_not_moving = sum < c.not_moving_distance;
+    }
+
+    // ---- events + done (sensors.py:443-489)
+    const bool reached_goal = false;                                   // EndlessGoal (plan.py:76-84)
+    const bool is_off_road = !(my_facts & SMX_FACT_ON_ROAD);           // sensors.py:498-500
+    const bool is_on_shoulder = ((my_facts >> SMX_FACT_CORNER_SHIFT) & 15) != 15;  // sensors.py:502-509
+    const bool reached_max = c.max_episode_steps > 0 && steps >= c.max_episode_steps;
+    bool is_off_route, is_wrong_way;
+    {
+      // sensors.py:527-594 with no route roads (endless mission)
+      double radius = sqrt(SMX_CHASSIS_LENGTH * SMX_CHASSIS_LENGTH + SMX_CHASSIS_WIDTH * SMX_CHASSIS_WIDTH) * 0.5 + 5.0;
+      int nl = (my_lane >= 0 && my_lane_dist < radius) ? my_lane : -1;
+      if (nl < 0) {
+        is_off_route = true;
+        is_wrong_way = false;
+      } else {
+        is_off_route = false;
+        is_wrong_way = false;
+        if (!m.lane_in_junction[nl] && !(a.debug_skip & 64)) {
+          double target = lane_heading_at_point(m, nl, px, py);
+          is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
+        }
+      }
+    }
+    uint8_t* ev = o.events + gid * SMX_EV_COUNT;
+    ev[SMX_EV_COLLISIONS] = collided ? 1 : 0;
+    ev[SMX_EV_OFF_ROAD] = is_off_road ? 1 : 0;
+    ev[SMX_EV_OFF_ROUTE] = is_off_route ? 1 : 0;
+    ev[SMX_EV_ON_SHOULDER] = is_on_shoulder ? 1 : 0;
+    ev[SMX_EV_WRONG_WAY] = is_wrong_way ? 1 : 0;
+    ev[SMX_EV_NOT_MOVING] = is_not_moving ? 1 : 0;
+    ev[SMX_EV_REACHED_GOAL] = reached_goal ? 1 : 0;
+    ev[SMX_EV_REACHED_MAX_EPISODE_STEPS] = reached_max ? 1 : 0;
+    ev[SMX_EV_AGENTS_ALIVE_DONE] = 0;
+    const uint32_t dc = c.done_criteria;
+    done = (is_off_road && (dc & SMX_DONE_OFF_ROAD)) || reached_goal || reached_max ||
+           (is_on_shoulder && (dc & SMX_DONE_ON_SHOULDER)) || (collided && (dc & SMX_DONE_COLLISION)) ||
+           (is_not_moving && (dc & SMX_DONE_NOT_MOVING)) || (is_off_route && (dc & SMX_DONE_OFF_ROUTE)) ||
+           (is_wrong_way && (dc & SMX_DONE_WRONG_WAY));
+    if (first) done = false;  // sensors.py:465: `not sim.resetting and (...)`: reset observations never end an agent
+
+    // ---- teardown (smarts.py:314, 329-363)
+    flags &= ~SMX_F_FIRST;
+    if (done) {
+      flags &= ~SMX_F_ALIVE;
+      atomicAdd(&env_new_done[env_local], 1);
+    }
     a.st.steps[gid] = steps;
-    a.st.flags[gid] = flags;
-    a.out.active[gid] = 1;
-    if (mode != 0) {
-      a.out.done[gid] = 0;
-      a.out.reward[gid] = 0.0;
-    }
-    if (slot == 0) {
-      a.st.env_episode[env] = episode;
-      a.st.env_done_count[env] = 0;
-      a.st.env_ticks[env] = env_ticks;
-      if (mode != 0) a.out.env_done[env] = 0;
+    // the trip-meter bit belongs to k_waypoints (same launch sequence, earlier kernel)
+    a.st.flags[gid] = (flags & ~SMX_F_TRIP_HAS_WP) | (a.st.flags[gid] & SMX_F_TRIP_HAS_WP);
+    o.active[gid] = done ? 0 : 1;
+    if (!a.keep_reward_done) o.done[gid] = done ? 1 : 0;
+  } else if (valid && !alive && !a.first_only) {
+    // an agent whose vehicle is gone: absent from the observations (zeros), done stays 0
+    if (o.active[gid] != 0 || o.done[gid] != 0) {
+      zero_dense_rows(a, gid);
+      o.done[gid] = 0;
+      o.active[gid] = 0;
     }
   }
+  __syncthreads();
+  if (valid && slot == 0) {
+    if (!a.first_only) {
+      int dcnt = a.st.env_done_count[env] + env_new_done[env_local];
+      a.st.env_done_count[env] = dcnt;
+      a.st.env_ticks[env] = a.st.env_ticks[env] + 1;
+      bool all_done = dcnt >= n_veh;  // hiway_env.py:258-261
+      o.env_done[env] = all_done ? 1 : 0;
+      a.st.env_reset_pending[env] = (all_done && c.auto_reset) ? 1 : 0;
+    } else if (!a.keep_reward_done) {
+      if (a.st.env_done_count[env] == 0 && pose[env_local * n_veh].alive) o.env_done[env] = 0;
+    }
+  }
+}
+
+// =================================================================================
+// k_reset: SMARTS.reset (smarts.py:365-460) for the selected envs — vehicles re-created at their
+// spawn poses (AckermannChassis._initialize_speed, chassis.py:668-671); the observation kernels
+// that follow produce their first observations.
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_reset(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  const int env = (int)(gid / c.num_vehicles);
+  const int slot = (int)(gid - (size_t)env * c.num_vehicles);
+  bool sel;
+  if (a.reset_all)
+    sel = true;
+  else if (a.env_mask)
+    sel = a.env_mask[env] != 0;
+  else
+    sel = a.st.env_reset_pending[env] != 0;
+  if (!sel) return;
+  const int episode = a.st.env_episode[env] + 1;  // every reset starts the next spawn row
+  const int row = a.sp.episodes > 0 ? (((episode % a.sp.episodes) + a.sp.episodes) % a.sp.episodes) : 0;
+  const double* sp = a.sp.pose + ((size_t)row * total + gid) * 4;
+  for (int f = 0; f < SMX_S_COUNT; ++f) SF(f) = 0.0;
+  SF(SMX_S_X) = sp[0];
+  SF(SMX_S_Y) = sp[1];
+  SF(SMX_S_HEADING) = wrap_heading(sp[2]);
+  SF(SMX_S_U) = sp[3];
+  SF(SMX_S_PREV_X) = sp[0];
+  SF(SMX_S_PREV_Y) = sp[1];
+  a.st.flags[gid] = SMX_F_ALIVE | SMX_F_FIRST;
+  a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
+  // per-env words are written by every thread of the env with the same values (no ordering needed
+  // inside this kernel; the env's own threads never read them here)
+  (void)slot;
+}
+
+// per-env bookkeeping of a reset, after k_reset (separate launch: k_reset's threads read env_episode)
+__global__ void __launch_bounds__(SMX_BLOCK) k_reset_env(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const int env = blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (env >= c.num_envs) return;
+  bool sel;
+  if (a.reset_all)
+    sel = true;
+  else if (a.env_mask)
+    sel = a.env_mask[env] != 0;
+  else
+    sel = a.st.env_reset_pending[env] != 0;
+  if (!sel) return;
+  a.st.env_episode[env] = a.st.env_episode[env] + 1;
+  a.st.env_done_count[env] = 0;
+  a.st.env_ticks[env] = c.reset_elapsed_steps;
+  a.st.env_reset_pending[env] = 0;
+  if (!a.keep_reward_done) a.out.env_done[env] = 0;
 }
 
 // =================================================================================
@@ -911,6 +1049,16 @@ static int fail(smx_handle h, int code, const std::string& msg) {
 
 extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; }
 
+#ifdef SMX_DEBUG_TIMING
+extern "C" int smx_prof_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  if (reset) {
+    unsigned long long z[24] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smx_prof), z, sizeof(z)) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif
 #ifdef SMX_DEBUG_BOUNDS
 extern "C" int smx_debug_read(int* site, long long* value) {
   if (hipMemcpyFromSymbol(site, HIP_SYMBOL(smx_dbg_site), sizeof(int)) != hipSuccess) return -2;
@@ -962,6 +1110,8 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
+  if ((c.sensors & SMX_SENSOR_WAYPOINTS) && (size_t)c.wp_paths * c.wp_len * 39 * (SMX_BLOCK / SMX_WP_LANES) > 96 * 1024)
+    return fail(h, SMX_ERR_INVALID, "waypoints: wp_paths * wp_len too large for the LDS staging area");
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (c.nb_max < 1 || c.nb_max > 127))
     return fail(h, SMX_ERR_INVALID, "neighbours: need 1 <= nb_max <= 127");
   hipError_t e = hipSetDevice(device);
@@ -1080,7 +1230,7 @@ extern "C" int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t 
 static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp, const smx_outputs* o) {
   if (!st || !sp || !o) return fail(h, SMX_ERR_INVALID, "null state / spawns / outputs");
   if (!st->f64 || !st->flags || !st->steps || !st->env_ticks || !st->env_done_count || !st->env_episode ||
-      !st->seed_cache)
+      !st->seed_cache || !st->facts_i32 || !st->facts_f64 || !st->env_reset_pending)
     return fail(h, SMX_ERR_INVALID, "null state buffer");
   if (!sp->pose || sp->episodes < 1) return fail(h, SMX_ERR_INVALID, "spawn table is empty");
   if (!o->ego_pos || !o->ego_f32 || !o->ego_lane || !o->events || !o->reward || !o->dist || !o->done || !o->active ||
@@ -1098,16 +1248,17 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   return SMX_OK;
 }
 
-static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* mask, const smx_state* st,
-                  const smx_spawns* sp, const smx_outputs* out, void* stream_) {
+static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint8_t* mask, const smx_state* st,
+                   const smx_spawns* sp, const smx_outputs* out, void* stream_) {
   if (!h) return SMX_ERR_INVALID;
   if (!h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_load_map has not been called");
   int rc = check_buffers(h, st, sp, out);
   if (rc != SMX_OK) return rc;
-  if (mode == 0 && !actions) return fail(h, SMX_ERR_INVALID, "null actions");
+  if (is_step && !actions) return fail(h, SMX_ERR_INVALID, "null actions");
   hipStream_t stream = (hipStream_t)stream_;
+  const smx_config& c = h->cfg;
   KernelArgs a;
-  a.cfg = h->cfg;
+  a.cfg = c;
   a.map = h->map;
   a.st = *st;
   a.sp = *sp;
@@ -1115,12 +1266,27 @@ static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* 
   a.actions = actions;
   a.env_mask = mask;
   a.lidar_rays = h->lidar_rays;
-  a.envs_per_block = SMX_BLOCK / h->cfg.num_vehicles;
+  a.first_only = 0;
+  a.keep_reward_done = 0;
+  a.reset_all = 0;
   a.heading_gain_pos = h->heading_gain_pos;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
-  const int blocks = (h->cfg.num_envs + a.envs_per_block - 1) / a.envs_per_block;
-  const bool timed = h->timing && mode == 0 && h->ev_used < 65536;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
+  const int scan_blocks = (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
+  const int vpb = SMX_BLOCK / SMX_WP_LANES;
+  const int wp_blocks = (int)((total + vpb - 1) / vpb);
+  const int epb = SMX_BLOCK / c.num_vehicles;
+  const int obs_blocks = (c.num_envs + epb - 1) / epb;
+  const int env_blocks = (c.num_envs + SMX_BLOCK - 1) / SMX_BLOCK;
+  size_t stage_bytes = 0;
+  if (c.sensors & SMX_SENSOR_WAYPOINTS) {
+    const size_t n = (size_t)c.wp_paths * c.wp_len;
+    const size_t per = ((n * 24 + n * 4 * 3 + n * 2 + n) + 15) & ~size_t(15);
+    stage_bytes = per * vpb;
+  }
+  const bool timed = h->timing && is_step && h->ev_used < 65536;
   if (timed) {
     if (h->ev_pool.size() < 2 * (h->ev_used + 1)) {
       hipEvent_t e0, e1;
@@ -1131,7 +1297,24 @@ static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* 
     }
     SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used], stream));
   }
-  hipLaunchKernelGGL(smx_tick_kernel, dim3(blocks), dim3(SMX_BLOCK), 0, stream, a, mode);
+  if (is_step) {
+    hipLaunchKernelGGL(k_control, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, a);
+    hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
+  }
+  if (!is_step || c.auto_reset) {
+    KernelArgs r = a;
+    r.first_only = 1;
+    r.keep_reward_done = is_step ? 1 : 0;
+    r.reset_all = (!is_step && mask == nullptr) ? 1 : 0;
+    r.env_mask = is_step ? nullptr : mask;
+    hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, r);
+    hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
+  }
   SMX_HIP(hipGetLastError());
   if (timed) {
     SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used + 1], stream));
@@ -1142,12 +1325,12 @@ static int launch(smx_handle h, int mode, const int8_t* actions, const uint8_t* 
 
 extern "C" int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, const smx_spawns* sp,
                          const smx_outputs* out, void* hip_stream) {
-  return launch(h, 1, nullptr, env_mask_dev, st, sp, out, hip_stream);
+  return enqueue(h, false, nullptr, env_mask_dev, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
                         const smx_outputs* out, void* hip_stream) {
-  return launch(h, 0, actions_dev, nullptr, st, sp, out, hip_stream);
+  return enqueue(h, true, actions_dev, nullptr, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_sync(smx_handle h, void* hip_stream) {

@@ -58,6 +58,20 @@ __device__ __noinline__ RoadFacts road_facts_scan(const MapDev& m, double px, do
     const int a = m.sg_off[SMX_BCHK(2, row + cx0, m.sg_nx * m.sg_ny + 1)], b = m.sg_off[SMX_BCHK(3, row + cx1 + 1, m.sg_nx * m.sg_ny + 1)];
     for (int k = a; k < b; ++k) {
       const smx_seg_rec s = m.sg_rec[SMX_BCHK(4, k, m.sg_off[m.sg_nx * m.sg_ny])];
+      // cheap exact-safe prefilter: the distance to the segment's bounding box bounds the
+      // distance to the segment from below.  A segment can only matter to the centre if it
+      // can beat (or tie) the current nearest lane or pass the road_with_point threshold, and
+      // to a corner only through that threshold.
+      {
+        const double bx0 = fmin(s.x1, s.x2), bx1 = fmax(s.x1, s.x2), by0 = fmin(s.y1, s.y2), by1 = fmax(s.y1, s.y2);
+        const double gx = fmax(fmax(bx0 - px, px - bx1), 0.0), gy2 = fmax(fmax(by0 - py, py - by1), 0.0);
+        const double lb2 = gx * gx + gy2 * gy2;
+        const double keep_c = fmin(fmax(out.dist, s.thr), radius) + 1e-6;
+        // corners sit within half a vehicle diagonal (< 2.0 m for every supported chassis) of the centre
+        const double keep_q = s.thr + 2.0 + 1e-6;
+        const double keep = n_corners > 0 ? fmax(keep_c, keep_q) : keep_c;
+        if (lb2 > keep * keep) continue;
+      }
       // distance_point_to_line(point, p1, p2) (math.py:393-411), shared segment length
       const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
       const double d = sqrt(ex * ex + ey * ey);
@@ -532,32 +546,42 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     const double qcum = jcum + sqrt(ex * ex + ey * ey);
     const double qh = uw.push(cur.heading);
     const int qlane = cur.lane;
-    // waypoints with jcum <= t < qcum interpolate on [j, j+1]
-    while (i < n_emit && t < qcum) {
-      WaypointOut o;
-      int dl;
-      if (t == jcum) {
-        o.x = jx;
-        o.y = jy;
-        o.heading = jh;
-        o.width = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)];
-        o.speed = m.lane_speed[jlane];
-        dl = strict_lane;
-      } else {
-        const double den = qcum - jcum, dt_ = t - jcum;
-        o.x = ((qx - jx) / den) * dt_ + jx;
-        o.y = ((qy - jy) / den) * dt_ + jy;
-        o.heading = ((qh - jh) / den) * dt_ + jh;
-        const double wj = m.lane_width[jlane], sj = m.lane_speed[jlane];
-        o.width = ((m.lane_width[qlane] - wj) / den) * dt_ + wj;
-        o.speed = ((m.lane_speed[qlane] - sj) / den) * dt_ + sj;
-        dl = jlane;
+    // waypoints with jcum <= t < qcum interpolate on [j, j+1]; np.interp's slope
+    // (dy[j+1] - dy[j]) / (dx[j+1] - dx[j]) is the same for every waypoint of the segment
+    if (i < n_emit && t < qcum) {
+      const double den = qcum - jcum;
+      const double sx = (qx - jx) / den, sy = (qy - jy) / den, sh = (qh - jh) / den;
+      const double wj = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)], sj = m.lane_speed[jlane];
+      double sw = 0.0, ss = 0.0;
+      if (qlane != jlane) {
+        sw = (m.lane_width[qlane] - wj) / den;
+        ss = (m.lane_speed[qlane] - sj) / den;
       }
-      o.heading = wrap_heading(o.heading);
-      o.lane = dl;
-      emit(i, o);
-      ++i;
-      t = (i == n - 1) ? D : (double)i * step;
+      do {
+        WaypointOut o;
+        int dl;
+        if (t == jcum) {
+          o.x = jx;
+          o.y = jy;
+          o.heading = jh;
+          o.width = wj;
+          o.speed = sj;
+          dl = strict_lane;
+        } else {
+          const double dt_ = t - jcum;
+          o.x = sx * dt_ + jx;
+          o.y = sy * dt_ + jy;
+          o.heading = sh * dt_ + jh;
+          o.width = sw * dt_ + wj;
+          o.speed = ss * dt_ + sj;
+          dl = jlane;
+        }
+        o.heading = wrap_heading(o.heading);
+        o.lane = dl;
+        emit(i, o);
+        ++i;
+        t = (i == n - 1) ? D : (double)i * step;
+      } while (i < n_emit && t < qcum);
     }
     if (qcum > jcum) strict_lane = jlane;
     jx = qx;

@@ -1,0 +1,320 @@
+// smx_scan.h — team-cooperative map scans: SMX_TEAM adjacent lanes of a wavefront serve ONE
+// vehicle.  The sweeps of the segment grid (nearest lane / road_with_point) and of the lanepoint
+// grid (10 nearest lanepoints, nearest lanepoint per lane) are embarrassingly parallel over grid
+// members; each lane takes every SMX_TEAM-th member and the team combines with xor-shuffles
+// (wave64 cross-lane ops, no LDS).  Results are identical to the one-thread forms in
+// smx_roadmap.h: all reductions are exact minima with the same (value, table index) tie order.
+#pragma once
+#include "smx_roadmap.h"
+
+#define SMX_TEAM 8
+
+__device__ __forceinline__ int team_rank() { return threadIdx.x & (SMX_TEAM - 1); }
+
+// lexicographic (value, index) minimum across the team; every lane receives the result
+__device__ __forceinline__ void team_min_pair(double& d, int& idx) {
+#pragma unroll
+  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) {
+    double od = __shfl_xor(d, msk, SMX_TEAM);
+    int oi = __shfl_xor(idx, msk, SMX_TEAM);
+    if (od < d || (od == d && oi < idx)) {
+      d = od;
+      idx = oi;
+    }
+  }
+}
+
+__device__ __forceinline__ int team_or(int v) {
+#pragma unroll
+  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) v |= __shfl_xor(v, msk, SMX_TEAM);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// road facts (see road_facts_scan): centre + 4 corners, one sweep, segments strided over the team
+// ---------------------------------------------------------------------------------
+__device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double py, double radius, int n_corners,
+                                            const double* cx, const double* cy) {
+  RoadFacts out;
+  out.lane = -1;
+  out.dist = SMX_INF;
+  out.on_road = false;
+  out.corner_mask = 0;
+  int lane_key = 0x7fffffff;  // lane id as tie key (INT_MAX = none)
+  int on_road = 0;
+  const int r = team_rank();
+  const double road_radius = fmax(5.0, 2.0 * m.default_lane_width);  // sumo_road_network.py:705
+  int cx0 = (int)floor((px - radius - m.sg_x0) / m.sg_cell);
+  int cx1 = (int)floor((px + radius - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((py - radius - m.sg_y0) / m.sg_cell);
+  int cy1 = (int)floor((py + radius - m.sg_y0) / m.sg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.sg_nx - 1);
+  cy1 = min(cy1, m.sg_ny - 1);
+  if (cx0 <= cx1) {
+    for (int gy = cy0; gy <= cy1; ++gy) {
+      const int row = gy * m.sg_nx;
+      const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
+      for (int k = a + r; k < b; k += SMX_TEAM) {
+        const smx_seg_rec s = m.sg_rec[k];
+        {
+          const double bx0 = fmin(s.x1, s.x2), bx1 = fmax(s.x1, s.x2), by0 = fmin(s.y1, s.y2), by1 = fmax(s.y1, s.y2);
+          const double gx = fmax(fmax(bx0 - px, px - bx1), 0.0), gy2 = fmax(fmax(by0 - py, py - by1), 0.0);
+          const double lb2 = gx * gx + gy2 * gy2;
+          const double keep_c = fmin(fmax(out.dist, s.thr), radius) + 1e-6;
+          const double keep_q = s.thr + 2.0 + 1e-6;
+          const double keep = n_corners > 0 ? fmax(keep_c, keep_q) : keep_c;
+          if (lb2 > keep * keep) continue;
+        }
+        const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
+        const double d = sqrt(ex * ex + ey * ey);
+        const double dd = d * d;
+        const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
+#pragma unroll
+        for (int q = -1; q < 4; ++q) {
+          if (q >= n_corners) break;
+          const double qx = q < 0 ? px : (q == 0 ? cx[0] : (q == 1 ? cx[1] : (q == 2 ? cx[2] : cx[3])));
+          const double qy = q < 0 ? py : (q == 0 ? cy[0] : (q == 1 ? cy[1] : (q == 2 ? cy[2] : cy[3])));
+          const double u = ((qx - s.x1) * sx) + ((qy - s.y1) * sy);
+          double offset;
+          if (d == 0.0 || u < 0.0 || u > dd) {
+            offset = (u < 0.0) ? 0.0 : d;
+          } else {
+            offset = u / d;
+          }
+          double dist;
+          if (offset == 0.0) {
+            const double fx = qx - s.x1, fy = qy - s.y1;
+            dist = sqrt(fx * fx + fy * fy);
+          } else {
+            const double uu = offset / d;
+            const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
+            const double fx = qx - ix, fy = qy - iy;
+            dist = sqrt(fx * fx + fy * fy);
+          }
+          if (q < 0) {
+            if (dist < radius) {
+              if (dist < out.dist || (dist == out.dist && s.lane < lane_key)) {
+                out.dist = dist;
+                lane_key = s.lane;
+              }
+              if (dist < road_radius && dist < s.thr) on_road = 1;
+            }
+          } else {
+            if (dist < road_radius && dist < s.thr) out.corner_mask |= (1 << q);
+          }
+        }
+      }
+    }
+  }
+  team_min_pair(out.dist, lane_key);
+  out.lane = lane_key == 0x7fffffff ? -1 : lane_key;
+  out.on_road = team_or(on_road) != 0;
+  out.corner_mask = team_or(out.corner_mask);
+  return out;
+}
+
+// ---------------------------------------------------------------------------------
+// lanepoint grid, members strided over the team
+// ---------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void lp_ring_visit_team(const MapDev& m, int cx, int cy, int r, int rank, F&& f) {
+  const int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+  for (int y = max(y0, 0); y <= min(y1, m.lpg_ny - 1); ++y) {
+    const int row = y * m.lpg_nx;
+    if (y == y0 || y == y1) {
+      const int xa = max(x0, 0), xb = min(x1, m.lpg_nx - 1);
+      if (xa > xb) continue;
+      const int a = m.lpg_off[row + xa], b = m.lpg_off[row + xb + 1];
+      for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+    } else {
+      if (x0 >= 0 && x0 < m.lpg_nx) {
+        const int a = m.lpg_off[row + x0], b = m.lpg_off[row + x0 + 1];
+        for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+      }
+      if (x1 != x0 && x1 >= 0 && x1 < m.lpg_nx) {
+        const int a = m.lpg_off[row + x1], b = m.lpg_off[row + x1 + 1];
+        for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+      }
+    }
+  }
+}
+
+// The 10 nearest lanepoints (see nearest10).  Each lane keeps the best 10 of its share; the team
+// merges by repeatedly taking the smallest head.  Every lane ends with the same Top10.
+__device__ inline void team_nearest10(const MapDev& m, double px, double py, Top10& res) {
+  const int K = 10;
+  double ld[K];
+  int li[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    ld[i] = SMX_INF;
+    li[i] = 0x7fffffff;
+  }
+  const int rank = team_rank();
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int keff = min(K, m.n_lanepoints);
+  const int rmax = lp_max_ring(m, cx, cy);
+  int r = 0;
+  for (;;) {
+    // two rings per merge: with 4 m cells the 10th neighbour is usually inside ring 2
+    const int r_end = min(rmax, r + (r == 0 ? 2 : 0));
+    for (; r <= r_end; ++r) {
+      lp_ring_visit_team(m, cx, cy, r, rank, [&](const smx_pt_rec& p) {
+        double dx = p.x - px, dy = p.y - py;
+        double d2 = dx * dx + dy * dy;
+        if (d2 < ld[K - 1] || (d2 == ld[K - 1] && p.idx < li[K - 1])) {
+          double cd = d2;
+          int ci = p.idx;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            bool lt = (cd < ld[k]) || (cd == ld[k] && ci < li[k]);
+            double td = lt ? ld[k] : cd;
+            int ti = lt ? li[k] : ci;
+            ld[k] = lt ? cd : ld[k];
+            li[k] = lt ? ci : li[k];
+            cd = td;
+            ci = ti;
+          }
+        }
+      });
+    }
+    // merge (on copies: the local lists keep growing if another ring is needed)
+    double hd[K];
+    int hi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      hd[i] = ld[i];
+      hi[i] = li[i];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      double wd = hd[0];
+      int wi = hi[0];
+      team_min_pair(wd, wi);
+      res.d2[j] = wd;
+      res.idx[j] = (wi == 0x7fffffff) ? -1 : wi;
+      const bool mine = (hi[0] == wi) && (wi != 0x7fffffff);
+#pragma unroll
+      for (int k = 0; k + 1 < K; ++k) {
+        hd[k] = mine ? hd[k + 1] : hd[k];
+        hi[k] = mine ? hi[k + 1] : hi[k];
+      }
+      if (mine) {
+        hd[K - 1] = SMX_INF;
+        hi[K - 1] = 0x7fffffff;
+      }
+    }
+    const int last = r - 1;  // last completed ring
+    bool full = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k == keff - 1) full = res.idx[k] >= 0 && ring_covers(m, last, res.d2[k]);
+    if (full || last >= rmax) break;
+  }
+}
+
+// Nearest lanepoint per key (lane or road), up to 4 keys at once (see closest_filtered4).
+__device__ inline void team_closest_filtered4(const MapDev& m, double px, double py, int k0, int k1, int k2, int k3,
+                                              int nkeys, bool by_road, int* out_idx, double* out_d2) {
+  double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const int rank = team_rank();
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int rmax = lp_max_ring(m, cx, cy);
+  double rd[4];
+  int ri[4];
+  for (int r = 0; r <= rmax; ++r) {
+    lp_ring_visit_team(m, cx, cy, r, rank, [&](const smx_pt_rec& p) {
+      const int key = by_road ? m.lane_road[p.lane] : p.lane;
+      double dx = p.x - px, dy = p.y - py;
+      double d2 = dx * dx + dy * dy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+        if (q < nkeys && key == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+          bd[q] = d2;
+          bi[q] = p.idx;
+        }
+      }
+    });
+    if (r < 1) continue;  // ring 0 alone never certifies
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      rd[q] = bd[q];
+      ri[q] = bi[q];
+      if (q < nkeys) {
+        team_min_pair(rd[q], ri[q]);
+        all = all && ri[q] != 0x7fffffff && ring_covers(m, r, rd[q]);
+      }
+    }
+    if (all) break;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double d = bd[q];
+    int i = bi[q];
+    if (q < nkeys) team_min_pair(d, i);
+    out_idx[q] = (q < nkeys && i != 0x7fffffff) ? i : -1;
+    if (out_d2) out_d2[q] = d;
+  }
+}
+
+// compute_path_seeds, team form (see smx_roadmap.h for the semantics)
+__device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
+                                                    double within_radius, bool has_route_object, const Top10& t) {
+  PathSeeds s;
+  s.f.n = 0;
+  s.f.road[0] = s.f.road[1] = -1;
+  s.road = -1;
+  s.n_lanes = 0;
+#pragma unroll
+  for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
+  bool routed = false;
+  if (has_route_object) {
+    int lp = pick_closest(m, t, heading, -1.0);
+    if (lp >= 0) {
+      int road = m.lane_road[m.lp_rec[lp].lane];
+      if (m.road_is_junction[road]) {
+        s.f.n = 1;
+        s.f.road[0] = road;
+        int nr = m.road_out_road[road];
+        if (nr >= 0) {
+          s.f.n = 2;
+          s.f.road[1] = nr;
+        }
+        int idx4[4];
+        double d24[4];
+        team_closest_filtered4(m, px, py, s.f.road[0], s.f.road[1], -9, -9, s.f.n, true, idx4, d24);
+        double bd = SMX_INF;
+        int best = -1;
+        for (int k = 0; k < s.f.n; ++k) {
+          double d = sqrt(d24[k]);
+          if (idx4[k] >= 0 && d < bd) {
+            bd = d;
+            best = idx4[k];
+          }
+        }
+        s.road = best >= 0 ? m.lane_road[m.lp_rec[best].lane] : -1;
+        routed = true;
+      }
+    }
+  }
+  if (!routed) {
+    int lp = pick_closest(m, t, heading, within_radius);
+    s.road = lp >= 0 ? m.lane_road[m.lp_rec[lp].lane] : -1;
+  }
+  if (s.road >= 0) {
+    const int la = m.road_lane_off[s.road], lb = m.road_lane_off[s.road + 1];
+    s.n_lanes = lb - la;
+    const int nk = min(s.n_lanes, SMX_SEED_LANES);
+    const int k0 = m.road_lanes[la], k1 = nk > 1 ? m.road_lanes[la + 1] : -9, k2 = nk > 2 ? m.road_lanes[la + 2] : -9,
+              k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
+    team_closest_filtered4(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
+  }
+  return s;
+}

@@ -131,7 +131,11 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
   int n_paths = 0;
   int best_path = 0;
   double best_d = SMX_INF;
+  int lane_first_path[SMX_SEED_LANES + 1] = {0, 0, 0, 0, 0};  // first path number of each seed lane
   for (int li = 0; li < seed.n_lanes; ++li) {
+#pragma unroll
+    for (int q = 0; q <= SMX_SEED_LANES; ++q)
+      if (q == li) lane_first_path[q] = n_paths;
     int start = seed_start(m, seed, li, px, py);
     if (start < 0) continue;
     BranchState bs;
@@ -166,6 +170,17 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
     int idx = 0;
     bool found = false;
     for (int li = 0; li < seed.n_lanes && !found; ++li) {
+      // skip whole lanes whose paths all come before the wanted one
+      if (li + 1 < seed.n_lanes && li + 1 <= SMX_SEED_LANES) {
+        int next_first = 0;
+#pragma unroll
+        for (int q = 0; q <= SMX_SEED_LANES; ++q)
+          if (q == li + 1) next_first = lane_first_path[q];
+        if (next_first <= want) {
+          idx = next_first;
+          continue;
+        }
+      }
       int start = seed_start(m, seed, li, px, py);
       if (start < 0) continue;
       BranchState bs;
@@ -360,7 +375,8 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
       v_new = r_new * SMX_AXLE_DIST;
     }
     double hd = s.heading;
-    double sh = sin(hd), ch = cos(hd);
+    double sh, ch;
+    sincos(hd, &sh, &ch);
     s.x += h * (-u_new * sh - v_new * ch);
     s.y += h * (u_new * ch - v_new * sh);
     s.heading = hd + h * r_new;

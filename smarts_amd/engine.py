@@ -208,6 +208,11 @@ class BatchedSim:
         st.driven_path = self.driven_path.data_ptr() if need_ring else None
         self.seed_cache = torch.full((nat.SEED_COUNT, E, N), -1, dtype=torch.int32, device=dev)
         st.seed_cache = self.seed_cache.data_ptr()
+        self.facts_i32 = torch.full((nat.FACT_I_COUNT, E, N), -1, dtype=torch.int32, device=dev)
+        self.facts_f64 = torch.zeros((nat.FACT_F_COUNT, E, N), dtype=torch.float64, device=dev)
+        self.env_reset_pending = torch.zeros((E,), dtype=torch.int32, device=dev)
+        st.facts_i32, st.facts_f64 = self.facts_i32.data_ptr(), self.facts_f64.data_ptr()
+        st.env_reset_pending = self.env_reset_pending.data_ptr()
         self._st = st
 
         # ---- spawns ----

@@ -1,0 +1,23 @@
+"""Developer: per-phase wave-clock breakdown of the tick kernel (build with -DSMX_DEBUG_TIMING)."""
+import os, sys, ctypes, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['SMX_LIBRARY'] = os.path.join(ROOT, 'smarts_amd', 'libsmarts_mi355x_prof.so')
+from smarts_amd.sumo_map import load_net
+from smarts_amd.map_compiler import compile_map
+from smarts_amd.engine import BatchedSim, SimConfig
+from smarts_amd import _native as nat
+E, N = int(sys.argv[1]), int(sys.argv[2]); scn = sys.argv[3] if len(sys.argv) > 3 else 'loop'
+cm = compile_map(load_net(os.path.join(ROOT, 'smarts_amd/scenarios', scn)))
+cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True)
+sim = BatchedSim(cm, cfg, spawn_episodes=2); lib = nat.load_library()
+sim.reset(); acts = torch.zeros((E, N), dtype=torch.int8, device='cuda')
+for _ in range(20): sim.step(acts)
+torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 24)(); lib.smx_prof_read(buf, 1)
+T = 50
+for _ in range(T): sim.step(acts)
+torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
+waves = (E * N + 63) // 64
+names = {0: 'total(step part)', 1: 'control', 2: 'dynamics', 3: 'pose scan+barrier', 4: 'collisions', 5: 'obs: ego/accel/neighbours', 6: 'obs: path seeds (NN)', 7: 'obs: trip init+waypoint paths', 8: 'obs: trip/driven/events', 9: 'observe total+store'}
+for k in range(10):
+    print(f'{names[k]:32s} {buf[k] / T / waves / 100.0:10.1f} us/wave (100 MHz clock)')
