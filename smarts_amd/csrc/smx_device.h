@@ -21,6 +21,7 @@ typedef smx_map_tables MapDev;
 __device__ int smx_dbg_site = 0;
 __device__ long long smx_dbg_value = 0;
 __device__ int smx_dbg_aux[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ double smx_dbg_f[64];
 #define SMX_BCHK(site, idx, n)                                                  \
   (((idx) < 0 || (long long)(idx) >= (long long)(n))                            \
        ? (atomicCAS(&smx_dbg_site, 0, (site)) == 0 ? (smx_dbg_value = (long long)(idx), 0) : 0) \

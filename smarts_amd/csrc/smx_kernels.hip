@@ -316,8 +316,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
     double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
     double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
-    PathSeeds seed = load_seeds(a, gid, total);
-    if (seed.road == -2) seed = compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true);
+    const PathSeeds seed = load_seeds(a, gid, total);  // found by k_scan at this very pose
     co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg, seed, knots, SMX_BLOCK);
   } else {
     // no action this tick: wheel torques do not persist, the steer motor target does
@@ -1065,6 +1064,10 @@ extern "C" int smx_debug_read(int* site, long long* value) {
   if (hipMemcpyFromSymbol(value, HIP_SYMBOL(smx_dbg_value), sizeof(long long)) != hipSuccess) return -2;
   int aux[8];
   if (hipMemcpyFromSymbol(aux, HIP_SYMBOL(smx_dbg_aux), sizeof(aux)) != hipSuccess) return -2;
+  double f[64];
+  if (hipMemcpyFromSymbol(f, HIP_SYMBOL(smx_dbg_f), sizeof(f)) != hipSuccess) return -2;
+  printf("dbg ctrl: wp_n=%g la_num=%g lax=%.6f lay=%.6f lah=%.6f n_paths=%g want=%g curv=%g\n", f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+  for (int k = 0; k < 17; ++k) printf("  wp%d %.6f %.6f %.6f\n", k, f[8 + 3 * k], f[9 + 3 * k], f[10 + 3 * k]);
   printf("dbg aux: first=%d remaining=%d hops=%d n_next=%d lane=%d next0=%d cur_idx=%d mem_next0=%d\n", aux[0], aux[1], aux[2], aux[3], aux[4], aux[5], aux[6], aux[7]);
   return 0;
 }

@@ -36,7 +36,7 @@ struct RoadFacts {
 // square, so it is listed in a visited cell.  Corners are at most half a vehicle diagonal from
 // the centre and only ask for segments closer than half a lane width, so the same sweep
 // answers them (n_corners = 0 skips them).
-__device__ __noinline__ RoadFacts road_facts_scan(const MapDev& m, double px, double py, double radius, int n_corners,
+__device__ inline RoadFacts road_facts_scan(const MapDev& m, double px, double py, double radius, int n_corners,
                                             const double* cx, const double* cy) {
   RoadFacts out;
   out.lane = -1;
@@ -163,7 +163,7 @@ struct Top10 {
   int idx[10];
 };
 
-__device__ __noinline__ void nearest10(const MapDev& m, double px, double py, Top10& t) {
+__device__ inline void nearest10(const MapDev& m, double px, double py, Top10& t) {
   const int K = 10;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -224,7 +224,7 @@ __device__ inline int pick_closest(const MapDev& m, const Top10& t, double headi
 
 // closest_linked_lanepoint_on_lane_to_point (lanepoints.py:629-636) for up to 4 lanes at once
 // (by_road == false), or closest_linked_lanepoint_on_road (:638-644) for up to 4 roads.
-__device__ __noinline__ void closest_filtered4(const MapDev& m, double px, double py, const int* keys, int nkeys,
+__device__ inline void closest_filtered4(const MapDev& m, double px, double py, const int* keys, int nkeys,
                                          bool by_road, int* out_idx, double* out_d2) {
   double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
   int bi[4] = {-1, -1, -1, -1};
@@ -620,7 +620,7 @@ struct PathSeeds {
 
 // has_route_object: the agent carries a (possibly empty) Route — the controller and the
 // waypoints sensor do; TripMeterSensor's constructor query does not.
-__device__ __noinline__ PathSeeds compute_path_seeds(const MapDev& m, double px, double py, double heading,
+__device__ inline PathSeeds compute_path_seeds(const MapDev& m, double px, double py, double heading,
                                                double within_radius, bool has_route_object) {
   PathSeeds s;
   s.f.n = 0;
