@@ -1,0 +1,119 @@
+"""Oracle: occupancy grid map and lidar sensors (test infrastructure).
+
+OGM — reference ``OGMSensor`` (``smarts/core/sensors.py:719-758``) over the Panda3D offscreen
+camera (``smarts/core/renderer.py:325-395``): an orthographic top-down render, centred on the
+vehicle, rotated with its heading (``sensors.py:670-672``), film size ``width*res x height*res``
+(``renderer.py:384-385``), alpha channel = 255 where a vehicle mesh covers the pixel, road hidden
+(``renderer.py:223``), rows flipped so that row 0 is ahead of the vehicle (``sensors.py:748``).
+Panda3D (an OpenGL rasteriser, not in the reference tree) is substituted by its sampling rule on
+the vehicles' footprints: a pixel is set iff its *centre* lies inside some vehicle's oriented
+chassis rectangle.  Pinned only by the reference's ±2 px checks (``test_observations.py:133-152``).
+
+Lidar — reference ``Lidar._compute_rays`` (``smarts/core/lidar.py:89-113``) restated line by line
+(including the quaternion-order quirk) and pinned by
+``tests/golden/lidar_rays.npz``; ``_trace_rays`` (``lidar.py:115-134``) = pybullet
+``rayTestBatch`` is substituted by exact ray / oriented-box and ray / ground-plane intersection
+(chassis box 1.47 x 3.68 x 1.0 centred 0.6 m above the base frame, ``models/vehicle.urdf``);
+the emitting vehicle itself is not hit (the ray starts inside its own box).
+"""
+import itertools
+import math
+
+import numpy as np
+
+from . import ref_math as rm
+from .dynamics import BASE_HEIGHT, CHASSIS_HEIGHT, CHASSIS_LENGTH, CHASSIS_WIDTH
+
+CHASSIS_BOX_Z = 0.6  # collision box origin above the base frame (models/vehicle.urdf)
+
+
+def ogm(ego, vehicles, width, height, resolution):
+    """(height, width) uint8 grid for `ego` (a VehicleBody); `vehicles` = all alive bodies (ego included)."""
+    grid = np.zeros((height, width), dtype=np.uint8)
+    h = ego.heading
+    right = np.array([math.cos(h), math.sin(h)])
+    fwd = np.array([-math.sin(h), math.cos(h)])
+    cols = (np.arange(width) + 0.5 - width / 2) * resolution   # x to the right of the vehicle
+    rows = (height / 2 - (np.arange(height) + 0.5)) * resolution  # y ahead of the vehicle
+    X, Y = np.meshgrid(cols, rows)
+    for v in vehicles:
+        d = np.array([v.x - ego.x, v.y - ego.y])
+        ex, ey = float(d @ right), float(d @ fwd)
+        dh = v.heading - h
+        vf = (-math.sin(dh), math.cos(dh))
+        vr = (math.cos(dh), math.sin(dh))
+        qx, qy = X - ex, Y - ey
+        inside = (np.abs(qx * vf[0] + qy * vf[1]) <= 0.5 * v.length) & (np.abs(qx * vr[0] + qy * vr[1]) <= 0.5 * v.width)
+        grid[inside] = 255
+    return grid
+
+
+def quaternion_from_euler(roll, pitch, yaw):
+    """pybullet.getQuaternionFromEuler -> (x, y, z, w)."""
+    cr, sr = math.cos(roll * 0.5), math.sin(roll * 0.5)
+    cp, sp = math.cos(pitch * 0.5), math.sin(pitch * 0.5)
+    cy, sy = math.cos(yaw * 0.5), math.sin(yaw * 0.5)
+    return (sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+            cr * cp * cy + sr * sp * sy)
+
+
+def base_rays(start_angle, end_angle, laser_angles, angle_resolution, max_distance):
+    """``Lidar._compute_rays`` (lidar.py:89-108): direction vectors of the base rays."""
+    n_rays = int((end_angle - start_angle) / angle_resolution)
+    yaws = -1 * np.asarray(laser_angles)
+    rolls = np.arange(n_rays) * angle_resolution
+    out = []
+    for yaw, roll in itertools.product(yaws, rolls):
+        rot = quaternion_from_euler(roll, 0, yaw)
+        out.append(rm.rotate_quat(np.asarray(rot, dtype=float), np.asarray((0, max_distance, 0), dtype=float)))
+    return np.array(out)
+
+
+def _ray_box(origin, direction, body):
+    """Smallest t in [0, 1] at which origin + t*direction enters the chassis box of `body`, or None."""
+    h = body.heading
+    f = np.array([-math.sin(h), math.cos(h), 0.0])
+    r = np.array([math.cos(h), math.sin(h), 0.0])
+    u = np.array([0.0, 0.0, 1.0])
+    c = np.array([body.x, body.y, BASE_HEIGHT + CHASSIS_BOX_Z])
+    half = (0.5 * CHASSIS_LENGTH, 0.5 * CHASSIS_WIDTH, 0.5 * CHASSIS_HEIGHT)
+    rel = origin - c
+    tmin, tmax = 0.0, 1.0
+    for axis, hw in zip((f, r, u), half):
+        o = float(rel @ axis)
+        d = float(direction @ axis)
+        if d == 0.0:
+            if abs(o) > hw:
+                return None
+            continue
+        t1, t2 = (-hw - o) / d, (hw - o) / d
+        if t1 > t2:
+            t1, t2 = t2, t1
+        tmin, tmax = max(tmin, t1), min(tmax, t2)
+        if tmin > tmax:
+            return None
+    return tmin
+
+
+def lidar(ego, others, rays, lidar_offset=(0.0, 0.0, 1.0)):
+    """Point cloud of one vehicle: (points [R,3] with inf on miss, hits [R] bool).
+
+    Origin = vehicle position + (0, 0, 1) (sensors.py:805-821); rays do not rotate with the
+    vehicle (lidar.py:109-113)."""
+    origin = np.array([ego.x, ego.y, BASE_HEIGHT]) + np.asarray(lidar_offset)
+    pts = np.full((len(rays), 3), np.inf)
+    hits = np.zeros(len(rays), dtype=bool)
+    for i, d in enumerate(rays):
+        best = None
+        if d[2] < 0.0:  # ground plane z = 0
+            t = -origin[2] / d[2]
+            if 0.0 <= t <= 1.0:
+                best = t
+        for b in others:
+            t = _ray_box(origin, d, b)
+            if t is not None and (best is None or t < best):
+                best = t
+        if best is not None:
+            hits[i] = True
+            pts[i] = origin + best * d
+    return pts, hits

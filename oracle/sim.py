@@ -26,6 +26,7 @@ import numpy as np
 
 from . import controller as ctl
 from . import ref_math as rm
+from . import sensors_extra as sx
 from .dynamics import VehicleBody
 
 COLLISION_LEEWAY = 0.05  # chassis.py:75-78
@@ -48,6 +49,8 @@ class AgentConfig:
     done_not_moving: bool = False
     not_moving_time: float = 60
     not_moving_distance: float = 1
+    ogm: Optional[tuple] = None  # (width, height, resolution) — OGM (agent_interface.py:42-51)
+    lidar_rays: Optional[np.ndarray] = None  # base rays [R, 3] (sensors_extra.base_rays)
 
 
 class _Agent:
@@ -270,6 +273,10 @@ class OracleEnv:
         o["distance_travelled"] = ag.dist_travelled
         ag.driven_path.append((self.elapsed_sim_time, b.position[:2]))  # sensors.py:842-847
         o["waypoint_paths"] = waypoint_paths if cfg.waypoints_lookahead is not None else None
+        if cfg.ogm is not None:  # sensors.py:303-305
+            o["ogm"] = sx.ogm(b, [ob for _, ob in alive_states], *cfg.ogm)
+        if cfg.lidar_rays is not None:  # sensors.py:297-301
+            o["lidar"] = sx.lidar(b, [ob for j, ob in alive_states if j != i], cfg.lidar_rays)
         done, events = self._is_done_with_events(ag)
         o["events"] = events
         o["dt"] = self.dt

@@ -690,6 +690,16 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
     }
     o.nb_count[gid] = 0;
   }
+  if ((c.sensors & SMX_SENSOR_OGM) && o.ogm) {
+    const size_t n = (size_t)c.ogm_width * c.ogm_height;
+    for (size_t k = 0; k < n; ++k) o.ogm[gid * n + k] = 0;
+  }
+  if ((c.sensors & SMX_SENSOR_LIDAR) && o.lidar_hit) {
+    for (int k = 0; k < c.lidar_rays; ++k) {
+      o.lidar_hit[gid * (size_t)c.lidar_rays + k] = 0;
+      for (int q = 0; q < 3; ++q) o.lidar_point[(gid * (size_t)c.lidar_rays + k) * 3 + q] = 0.0;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
@@ -960,6 +970,167 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
 }
 
 // =================================================================================
+// k_ogm: occupancy grid map sensor (OGMSensor, sensors.py:719-758): one wavefront per observing
+// vehicle.  The H x W byte tile is built in LDS (lane j rasterises env-mate j's footprint over the
+// few pixels its bounding rectangle touches) and leaves as full 16-byte pieces — the kernel is
+// bound by its own 4 KiB-per-agent output stream.  Pixel rule (substitution for the Panda3D
+// orthographic render, renderer.py:325-395): a pixel is 255 iff its centre lies inside a vehicle's
+// oriented chassis rectangle; view centred on the vehicle, +row = behind, row 0 = ahead
+// (np.flipud, sensors.py:748), extent width*res x height*res (renderer.py:384-385).
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) {
+  extern __shared__ __align__(16) unsigned char tile[];
+  const smx_config& c = a.cfg;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = blockIdx.x;
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  const bool live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
+  if (!live) return;  // uniform for the whole workgroup
+  const int W = c.ogm_width, H = c.ogm_height;
+  const int n_veh = c.num_vehicles;
+  const int env = (int)(gid / n_veh);
+  const int bytes = W * H;
+  for (int k = threadIdx.x; k < bytes / 4; k += SMX_BLOCK) reinterpret_cast<int*>(tile)[k] = 0;
+  __syncthreads();
+  const double res = c.ogm_resolution;
+  const double ex0 = SF(SMX_S_X), ey0 = SF(SMX_S_Y), eh = wrap_heading(SF(SMX_S_HEADING));
+  const double rx = cos(eh), ry = sin(eh);    // ego right axis
+  const double fx = -sin(eh), fy = cos(eh);   // ego forward axis
+  for (int j = threadIdx.x; j < n_veh; j += SMX_BLOCK) {
+    const size_t og = (size_t)env * n_veh + j;
+    if (!(a.st.flags[og] & SMX_F_ALIVE)) continue;
+    const double vx = a.st.f64[(size_t)SMX_S_X * total + og], vy = a.st.f64[(size_t)SMX_S_Y * total + og];
+    const double vh = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
+    const double dx = vx - ex0, dy = vy - ey0;
+    const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
+    const double dh = vh - eh;
+    const double vfx = -sin(dh), vfy = cos(dh), vrx = cos(dh), vry = sin(dh);
+    const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
+    const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
+    // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
+    int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
+    int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) / res) + 1;
+    c0 = max(c0, 0);
+    r0 = max(r0, 0);
+    c1 = min(c1, W - 1);
+    r1 = min(r1, H - 1);
+    for (int r = r0; r <= r1; ++r) {
+      const double py = (0.5 * H - (r + 0.5)) * res - cy;
+      for (int col = c0; col <= c1; ++col) {
+        const double px = (col + 0.5 - 0.5 * W) * res - cx;
+        if (fabs(px * vfx + py * vfy) <= hl && fabs(px * vrx + py * vry) <= hw) tile[r * W + col] = 255;
+      }
+    }
+  }
+  __syncthreads();
+  int4* dst = reinterpret_cast<int4*>(a.out.ogm + gid * (size_t)bytes);
+  for (int k = threadIdx.x; k < bytes / 16; k += SMX_BLOCK) dst[k] = reinterpret_cast<const int4*>(tile)[k];
+}
+
+// =================================================================================
+// k_lidar: lidar sensor (LidarSensor sensors.py:797-827, Lidar lidar.py:58-134): one wavefront per
+// observing vehicle, lanes over rays.  Ray i = [origin, origin + base_ray[i]], origin = vehicle
+// position + (0, 0, 1); base rays come from the host (they do not rotate with the vehicle,
+// lidar.py:109-113).  pybullet rayTestBatch is substituted by exact ray / oriented-box and
+// ray / ground-plane intersection (DESIGN.md "Substitutions"); a miss reports (inf, inf, inf).
+// =================================================================================
+struct LidarPose {
+  double x, y, fx, fy;  // centre, forward axis
+  int alive;
+};
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
+  __shared__ LidarPose mates[SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = blockIdx.x;
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  const bool live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
+  if (!live) return;
+  const int n_veh = c.num_vehicles;
+  const int env = (int)(gid / n_veh);
+  const int slot = (int)(gid - (size_t)env * n_veh);
+  if (threadIdx.x < n_veh) {
+    const size_t og = (size_t)env * n_veh + threadIdx.x;
+    LidarPose p;
+    p.x = a.st.f64[(size_t)SMX_S_X * total + og];
+    p.y = a.st.f64[(size_t)SMX_S_Y * total + og];
+    const double h = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
+    p.fx = -sin(h);
+    p.fy = cos(h);
+    p.alive = (a.st.flags[og] & SMX_F_ALIVE) ? 1 : 0;
+    mates[threadIdx.x] = p;
+  }
+  __syncthreads();
+  const double ox = SF(SMX_S_X), oy = SF(SMX_S_Y), oz = SMX_BASE_HEIGHT + 1.0;
+  const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH, hh = 0.5 * SMX_CHASSIS_HEIGHT;
+  const double bz = SMX_BASE_HEIGHT + 0.6;  // chassis box centre height (models/vehicle.urdf)
+  for (int i = threadIdx.x; i < c.lidar_rays; i += SMX_BLOCK) {
+    const double dx = a.lidar_rays[i * 3 + 0], dy = a.lidar_rays[i * 3 + 1], dz = a.lidar_rays[i * 3 + 2];
+    double best = SMX_INF;
+    if (dz < 0.0) {
+      const double t = -oz / dz;
+      if (t >= 0.0 && t <= 1.0) best = t;
+    }
+    for (int j = 0; j < n_veh; ++j) {
+      if (j == slot) continue;
+      const LidarPose p = mates[j];
+      if (!p.alive) continue;
+      const double relx = ox - p.x, rely = oy - p.y, relz = oz - bz;
+      // slabs along the box axes: forward f, right r = (f.y, -f.x), up
+      double tmin = 0.0, tmax = 1.0;
+      bool miss = false;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double o, d, half;
+        if (ax == 0) {
+          o = relx * p.fx + rely * p.fy;
+          d = dx * p.fx + dy * p.fy;
+          half = hl;
+        } else if (ax == 1) {
+          o = relx * p.fy + rely * (-p.fx);
+          d = dx * p.fy + dy * (-p.fx);
+          half = hw;
+        } else {
+          o = relz;
+          d = dz;
+          half = hh;
+        }
+        if (d == 0.0) {
+          if (fabs(o) > half) miss = true;
+        } else {
+          double t1 = (-half - o) / d, t2 = (half - o) / d;
+          if (t1 > t2) {
+            double tt = t1;
+            t1 = t2;
+            t2 = tt;
+          }
+          tmin = fmax(tmin, t1);
+          tmax = fmin(tmax, t2);
+          if (tmin > tmax) miss = true;
+        }
+      }
+      if (!miss && tmin < best) best = tmin;
+    }
+    const size_t q = gid * (size_t)c.lidar_rays + i;
+    if (best <= 1.0) {
+      a.out.lidar_hit[q] = 1;
+      a.out.lidar_point[q * 3 + 0] = ox + best * dx;
+      a.out.lidar_point[q * 3 + 1] = oy + best * dy;
+      a.out.lidar_point[q * 3 + 2] = oz + best * dz;
+    } else {
+      a.out.lidar_hit[q] = 0;
+      const double inf = __builtin_huge_val();
+      a.out.lidar_point[q * 3 + 0] = inf;
+      a.out.lidar_point[q * 3 + 1] = inf;
+      a.out.lidar_point[q * 3 + 2] = inf;
+    }
+  }
+}
+
+// =================================================================================
 // k_reset: SMARTS.reset (smarts.py:365-460) for the selected envs — vehicles re-created at their
 // spawn poses (AckermannChassis._initialize_speed, chassis.py:668-671); the observation kernels
 // that follow produce their first observations.
@@ -1115,6 +1286,12 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) && (size_t)c.wp_paths * c.wp_len * 39 * (SMX_BLOCK / SMX_WP_LANES) > 96 * 1024)
     return fail(h, SMX_ERR_INVALID, "waypoints: wp_paths * wp_len too large for the LDS staging area");
+  if ((c.sensors & SMX_SENSOR_OGM) &&
+      (c.ogm_width < 1 || c.ogm_height < 1 || (c.ogm_width * c.ogm_height) % 16 != 0 ||
+       c.ogm_width * c.ogm_height > 64 * 1024 || !(c.ogm_resolution > 0.0)))
+    return fail(h, SMX_ERR_INVALID, "ogm: need width*height a multiple of 16 and at most 65536, resolution > 0");
+  if ((c.sensors & SMX_SENSOR_LIDAR) && (c.lidar_rays < 1 || c.lidar_rays > 65536))
+    return fail(h, SMX_ERR_INVALID, "lidar: need 1 <= lidar_rays <= 65536");
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (c.nb_max < 1 || c.nb_max > 127))
     return fail(h, SMX_ERR_INVALID, "neighbours: need 1 <= nb_max <= 127");
   hipError_t e = hipSetDevice(device);
@@ -1246,6 +1423,11 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (!o->nb_pos || !o->nb_box || !o->nb_heading || !o->nb_speed ||
                                              !o->nb_lane_index || !o->nb_lane_id || !o->nb_slot || !o->nb_count))
     return fail(h, SMX_ERR_INVALID, "neighbourhood sensor enabled but an output buffer is null");
+  if ((c.sensors & SMX_SENSOR_OGM) && !o->ogm) return fail(h, SMX_ERR_INVALID, "ogm sensor enabled but out.ogm is null");
+  if ((c.sensors & SMX_SENSOR_LIDAR) && (!o->lidar_hit || !o->lidar_point))
+    return fail(h, SMX_ERR_INVALID, "lidar sensor enabled but an output buffer is null");
+  if ((c.sensors & SMX_SENSOR_LIDAR) && !h->lidar_rays)
+    return fail(h, SMX_ERR_STATE, "lidar sensor enabled but smx_set_lidar_rays has not been called");
   if ((c.done_criteria & SMX_DONE_NOT_MOVING) && !st->driven_path)
     return fail(h, SMX_ERR_INVALID, "not_moving done criterion needs the driven_path ring");
   return SMX_OK;
@@ -1303,6 +1485,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
   if (is_step) {
     hipLaunchKernelGGL(k_control, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    if (c.sensors & SMX_SENSOR_OGM)
+      hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, a);
+    if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, a);
     hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, a);
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
   }
@@ -1315,6 +1500,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
     hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    if (c.sensors & SMX_SENSOR_OGM)
+      hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, r);
+    if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, r);
     hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, r);
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
+from .lidar import SensorParams, base_rays, ray_count
 from .map_compiler import CompiledMap
 
 
@@ -45,6 +46,11 @@ class SimConfig:
     not_moving_distance: float = 1.0
     auto_reset: bool = False  # parallel_env.py:62
     track_driven_path: bool = True
+    ogm: bool = False  # agent_interface.py:42-51 (OGM defaults 256 x 256 @ 50/256)
+    ogm_width: int = 256
+    ogm_height: int = 256
+    ogm_resolution: float = 50 / 256
+    lidar: Optional[SensorParams] = None  # agent_interface.py:132-135
 
     def sensors_mask(self) -> int:
         m = 0
@@ -54,6 +60,10 @@ class SimConfig:
             m |= nat.SENSOR_NEIGHBORS
         if self.accelerometer:
             m |= nat.SENSOR_ACCELEROMETER
+        if self.ogm:
+            m |= nat.SENSOR_OGM
+        if self.lidar is not None:
+            m |= nat.SENSOR_LIDAR
         return m
 
     def done_mask(self) -> int:
@@ -183,6 +193,10 @@ class BatchedSim:
         c.not_moving_time, c.not_moving_distance = cfg.not_moving_time, cfg.not_moving_distance
         c.auto_reset = 1 if cfg.auto_reset else 0
         c.reset_elapsed_steps = cfg.reset_elapsed_steps()
+        if cfg.ogm:
+            c.ogm_width, c.ogm_height, c.ogm_resolution = cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution
+        if cfg.lidar is not None:
+            c.lidar_rays, c.lidar_max_distance = ray_count(cfg.lidar), cfg.lidar.max_distance
         self._c = c
         self.handle = C.c_void_p()
         rc = self.lib.smx_create(C.byref(c), idx, C.byref(self.handle))
@@ -190,6 +204,10 @@ class BatchedSim:
         tables, keep = map_tables_struct(cm)
         nat.check(self.lib, self.handle, self.lib.smx_load_map(self.handle, C.byref(tables)), "smx_load_map")
         del keep
+        if cfg.lidar is not None:
+            self.lidar_rays = torch.from_numpy(base_rays(cfg.lidar)).to(dev)
+            rc = self.lib.smx_set_lidar_rays(self.handle, self.lidar_rays.data_ptr(), int(self.lidar_rays.shape[0]))
+            nat.check(self.lib, self.handle, rc, "smx_set_lidar_rays")
 
         # ---- state ----
         T = E * N
@@ -256,6 +274,12 @@ class BatchedSim:
             o["nb_lane_id"] = z((E, N, K), torch.int16)
             o["nb_slot"] = z((E, N, K), torch.int8)
             o["nb_count"] = z((E, N), torch.uint8)
+        if cfg.ogm:
+            o["ogm"] = z((E, N, cfg.ogm_height, cfg.ogm_width), torch.uint8)
+        if cfg.lidar is not None:
+            R = ray_count(cfg.lidar)
+            o["lidar_hit"] = z((E, N, R), torch.uint8)
+            o["lidar_point"] = z((E, N, R, 3), torch.float64)
         self.out = o
         so = nat.SmxOutputs()
         for name in nat.OUTPUT_FIELDS:

@@ -354,6 +354,24 @@ def dump_controller(rn, net, rng, n):
     return out
 
 
+def dump_lidar_rays():
+    """Reference Lidar._compute_rays (lidar.py:89-113) for BasicLidar and the 100-ray planar
+    sensor of BASELINE config 5."""
+    from smarts.core.lidar import Lidar
+    from smarts.core.lidar_sensor_params import BasicLidar, SensorParams
+
+    planar = SensorParams(start_angle=0, end_angle=2 * np.pi, laser_angles=np.array([0.0]),
+                          angle_resolution=2 * np.pi / 100.5, max_distance=20, noise_mu=0, noise_sigma=0.078)
+    out = {}
+    for name, params in (("basic", BasicLidar), ("planar100", planar)):
+        origin = np.array([3.0, -7.0, 1.5])
+        lidar = Lidar(origin, params, None)
+        rays = lidar._compute_rays()
+        out[name] = np.array([d - origin for (_, d) in rays])
+        out[name + "_origin_ok"] = np.array(all((o == origin).all() for (o, _) in rays))
+    return out
+
+
 SCENARIOS = {
     "loop": "scenarios/loop",
     "4lane": "scenarios/intersections/4lane",
@@ -366,6 +384,11 @@ def main():
     from smarts_amd.sumo_map import load_net
 
     logging.basicConfig(level=logging.WARNING)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "lidar"):
+        np.savez_compressed(os.path.join(OUT, "lidar_rays.npz"), **dump_lidar_rays())
+        print("lidar rays written")
+    if os.environ.get("GOLDEN_ONLY", "") == "lidar":
+        return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))
         rn = make_reference_road_network(net)

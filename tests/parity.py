@@ -22,7 +22,15 @@ def oracle_config(cfg):
         done_not_moving=cfg.done_not_moving,
         not_moving_time=cfg.not_moving_time,
         not_moving_distance=cfg.not_moving_distance,
+        ogm=(cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution) if cfg.ogm else None,
+        lidar_rays=oracle_lidar_rays(cfg.lidar) if cfg.lidar is not None else None,
     )
+
+
+def oracle_lidar_rays(p):
+    from oracle.sensors_extra import base_rays
+
+    return base_rays(p.start_angle, p.end_angle, p.laser_angles, p.angle_resolution, p.max_distance)
 
 
 def empty_dense(cfg, n):
@@ -46,6 +54,13 @@ def empty_dense(cfg, n):
             nb_lane_id=np.full((n, K), -1, np.int16), nb_slot=np.full((n, K), -1, np.int8),
             nb_count=np.zeros(n, np.uint8),
         )
+    if cfg.ogm:
+        d["ogm"] = np.zeros((n, cfg.ogm_height, cfg.ogm_width), np.uint8)
+    if cfg.lidar is not None:
+        from smarts_amd.lidar import ray_count
+
+        d["lidar_hit"] = np.zeros((n, ray_count(cfg.lidar)), np.uint8)
+        d["lidar_point"] = np.zeros((n, ray_count(cfg.lidar), 3))
     return d
 
 
@@ -106,11 +121,17 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
                 d["nb_lane_index"][i, k] = nv["lane_index"] if nv["lane_index"] is not None else -1
                 d["nb_lane_id"][i, k] = lane_no[nv["lane_id"]] if nv["lane_id"] is not None else -1
                 d["nb_slot"][i, k] = nv["slot"]
+        if cfg.ogm:
+            d["ogm"][i] = o["ogm"]
+        if cfg.lidar is not None:
+            pts, hits = o["lidar"]
+            d["lidar_hit"][i] = hits
+            d["lidar_point"][i] = pts
     return d
 
 
 INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
-            "nb_lane_id", "nb_slot", "nb_count"]
+            "nb_lane_id", "nb_slot", "nb_count", "ogm", "lidar_hit"]
 
 
 def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
@@ -125,7 +146,10 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
                            f"oracle={a[tuple(idx[0])]} dev={b[tuple(idx[0])]}")
         else:
             tol = tol32 if a.dtype == np.float32 else tol64
-            err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+            with np.errstate(invalid="ignore"):
+                err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+            err = np.where(np.isinf(a) & (a == b), 0.0, err)  # lidar misses are +inf on both sides
+            err = np.where(np.isnan(err), np.inf, err)
             if a.dtype == np.float32:
                 err = err / np.maximum(1.0, np.abs(a.astype(np.float64)))
             if err.size and err.max() > tol:

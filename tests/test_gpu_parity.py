@@ -56,6 +56,40 @@ def test_teacher_forced_ticks(name, E, N, T, seed, nets, compiled_maps):
     sim.close()
 
 
+@pytest.mark.parametrize("name,E,N,T,seed,sensor", [("loop", 2, 32, 20, 31, "ogm"), ("minicity", 2, 32, 20, 32, "lidar"),
+                                                     ("4lane", 2, 16, 12, 33, "basic_lidar+ogm")])
+def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps):
+    """BASELINE.json configs[3] (OGM 64 x 64 over 50 m) and configs[4] (100-ray planar lidar) at
+    oracle-sized batches: grids and hit flags bit-exact, hit points to 1e-9."""
+    import torch
+
+    from smarts_amd.lidar import BasicLidar, Planar100
+
+    kw = {}
+    if "ogm" in sensor:
+        kw.update(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
+    if "lidar" in sensor:
+        kw.update(lidar=BasicLidar if "basic" in sensor else Planar100)
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, **kw)
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    if "ogm" in sensor:
+        assert d["ogm"].reshape(E * N, 64, 64)[:, 31:33, 31:33].min() == 255  # own footprint at the centre
+    rng = np.random.default_rng(seed)
+    seen_hits = 0
+    for t in range(T):
+        acts = _actions(rng, E, N)
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{name} {sensor} t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        if "lidar" in sensor:
+            seen_hits += int(d["lidar_hit"].sum())
+        parity.sync_oracle_from_device(ob, sim)
+    if "lidar" in sensor:
+        assert seen_hits > 0
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 

@@ -139,3 +139,22 @@ def test_lane_following_controller_matches_reference(name, oracle_maps):
                 assert st.min_curvature_location[1] == g["out_mcl_y"][i]
     finally:
         OLanePoints.tie_rule = "index"
+
+
+def test_lidar_base_rays_match_reference():
+    """Lidar._compute_rays (lidar.py:89-113) dumped by tests/golden/gen_golden.py: the oracle's
+    line-by-line restatement and the product's closed form (smarts_amd/lidar.py) both reproduce it."""
+    import os
+
+    from oracle.sensors_extra import base_rays as oracle_rays
+    from smarts_amd.lidar import BasicLidar, Planar100, base_rays, ray_count
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lidar_rays.npz"))
+    for params, key in ((BasicLidar, "basic"), (Planar100, "planar100")):
+        ref = g[key]
+        ora = oracle_rays(params.start_angle, params.end_angle, params.laser_angles, params.angle_resolution,
+                          params.max_distance)
+        assert ora.shape == ref.shape == (ray_count(params), 3)
+        assert np.abs(ora - ref).max() < 1e-13  # the dump stores (direction + origin) - origin
+        assert np.abs(base_rays(params) - ref).max() < 1e-13
+        assert np.allclose(np.linalg.norm(ref, axis=1), params.max_distance, atol=1e-12)
