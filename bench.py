@@ -6,11 +6,19 @@
 
 A "step" is one SMARTS tick of every environment instance of the shard: controllers, vehicle
 dynamics, collisions, sensors/observation build, events/reward/done and auto-reset — one
-``smx_step`` launch.  Workload at every N: BASELINE config[1] per GPU — scenarios/loop, 1024
-batched envs x 8 Laner agents, waypoints (4, 20) + neighbourhood (10, 50 m) observations,
-dt = 0.1 s, synthetic spawns / action stream per SURVEY.md §8d (weak scaling: each rank owns
-its own 1024 envs; no data-path collective, only the small reward/done gather).
+``smx_step`` call, which enqueues the tick's kernels (k_control, k_scan, [k_ogm], [k_lidar],
+k_waypoints, k_observe and, with auto-reset, the reset pass) on one stream.
+Workload at every N: BASELINE configs[1] per GPU — scenarios/loop, 1024 batched envs x 8 Laner
+agents, waypoints (4, 20) + neighbourhood (10, 50 m) observations, dt = 0.1 s, synthetic
+spawns / action stream per SURVEY.md §8d (weak scaling: each rank owns its own 1024 envs; no
+data-path collective, only the small reward/done gather).  ``--config c3|c4|c5`` selects the
+other BASELINE configurations (at ``--envs-per-gpu`` of your choice) for profiling; the default
+line is always configs[1].
 Inputs (state, spawn table, action stream) are resident in HBM when the timed region starts.
+
+After the timed region a short second pass (not timed, not part of ``value``) re-runs the tick
+with a boundary event after every kernel to attribute the time per kernel (``roofline.kernels``)
+and to report obs-build ms/tick.
 """
 import argparse
 import json
@@ -40,6 +48,32 @@ def action_stream(E, N, seed, first_env):
     return out
 
 
+# BASELINE.json configs[1..4]: scenario, envs per GPU, vehicles per env, extra sensors
+CONFIGS = {
+    "c2": dict(scenario="loop", envs=1024, vehicles=8, extra={}, label="configs[1]"),
+    "c3": dict(scenario="intersections/4lane", envs=2048, vehicles=16, extra={}, label="configs[2]"),
+    "c4": dict(scenario="loop", envs=4096, vehicles=32,
+               extra=dict(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64), label="configs[3]"),
+    "c5": dict(scenario="minicity", envs=4096, vehicles=64, extra=dict(lidar="planar100"), label="configs[4]"),
+}
+
+
+def hbm_traffic_for(workload_key):
+    """HBM bytes per smx_step from the committed PMC passes (profiles/*_hbm_traffic.json, written
+    by tools/collect_hbm_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command).  None when no pass was recorded for this workload."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload_key") == workload_key:
+            return rec
+    return None
+
+
 def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
     """The CPU port (oracle/: per-agent sequential Python/numpy, the shape of SMARTS._step) timed
     on a bounded sample of the same workload.  Reported, never shipped."""
@@ -47,7 +81,8 @@ def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
     import parity
     from smarts_amd.engine import SimConfig, make_spawns
 
-    E, N = 4, cfg_kw["num_vehicles"]
+    N = cfg_kw["num_vehicles"]
+    E = 4 if N <= 8 else 1
     kw = dict(cfg_kw)
     kw["num_envs"] = E
     cfg = SimConfig(**kw)
@@ -68,8 +103,9 @@ def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
         "unit": "env-steps/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{E} envs x {N} agents x {ticks} ticks of the same workload (scenarios/loop, waypoints+neighbours), "
-                  f"{el:.1f} s on one host core; the reference itself is single-threaded Python per env",
+        "sample": f"{E} envs x {N} agents x {ticks} ticks of the same workload (same map, sensors, spawns and "
+                  f"action stream), {el:.1f} s on one host core; the reference itself is single-threaded Python "
+                  "per env",
     }
 
 
@@ -78,9 +114,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=1024)
-    ap.add_argument("--vehicles", type=int, default=8)
-    ap.add_argument("--scenario", default="loop")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--vehicles", type=int, default=None)
+    ap.add_argument("--scenario", default=None)
+    ap.add_argument("--phase-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,12 +139,20 @@ def main():
     if world > 1:
         dist.barrier()
 
-    E, N = args.envs_per_gpu, args.vehicles
+    from smarts_amd import lidar as lidar_mod
+
+    preset = CONFIGS[args.config]
+    E = args.envs_per_gpu or preset["envs"]
+    N = args.vehicles or preset["vehicles"]
+    scenario = args.scenario or preset["scenario"]
     plan = sharding.ShardPlan(total_envs=E * world, world_size=world, rank=rank)
-    net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", args.scenario))
+    net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", scenario))
     cm = compile_map(net)
     cfg_kw = dict(num_envs=E, num_vehicles=N, dt=0.1, waypoints=True, neighbors=True, nb_radius=50.0, nb_max=10,
                   wp_paths=4, wp_len=20, wp_lookahead=32, auto_reset=True)
+    cfg_kw.update(preset["extra"])
+    if cfg_kw.get("lidar") == "planar100":
+        cfg_kw["lidar"] = lidar_mod.Planar100
     cfg = SimConfig(**cfg_kw)
     spawns = make_spawns(cm, E, N, episodes=4, seed=42, first_env=plan.first_env)
     sim = BatchedSim(cm, cfg, device=device, spawns=spawns)
@@ -139,15 +185,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-kernel attribution pass (outside the timed region)
+    phase_ms = None
+    if rank == 0 and args.phase_steps > 0:
+        sim.set_timing(2)
+        for i in range(args.phase_steps):
+            sim.step(actions[(args.warmup + args.steps + i) % ACTION_CYCLE])
+        torch.cuda.synchronize()
+        phase_ms = sim.read_phase_ms().mean(axis=0)
+        sim.set_timing(0)
+
     if rank == 0:
         total_envs = E * world
         env_steps_per_s = total_envs * args.steps / elapsed
         # algorithmic bytes of one launch: per agent-step, state read + state write + action +
         # every observation / reward / done byte written (dense StdObs layout)
-        bytes_agent = 2 * sim.state_bytes_per_agent_step() + 1 + sim.output_bytes_per_agent_step()
+        kb = sim.kernel_bytes_per_agent_step()
+        bytes_agent = sum(kb.values())
         bytes_launch = bytes_agent * E * N
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         achieved = bytes_launch / avg_kernel_s / 1e9
+        workload_key = f"{args.config}:{scenario}:{E}x{N}"
+        traffic = hbm_traffic_for(workload_key)
+        kernels = None
+        obs_build_ms = None
+        dominant = None
+        if phase_ms is not None:
+            from smarts_amd._native import PHASES
+
+            kernels = {}
+            for name, ms in zip(PHASES, phase_ms):
+                ms = float(ms)
+                if name in ("ogm", "lidar") and name not in kb:
+                    continue
+                b = kb.get(name, 0) * E * N
+                kernels["k_" + name if name != "reset" else "reset_pass"] = {
+                    "avg_ms": ms, "algorithmic_bytes": b,
+                    "GB/s": (b / (ms * 1e-3) / 1e9) if ms > 0 and b else None,
+                }
+            obs_build_ms = float(sum(ms for n_, ms in zip(PHASES, phase_ms) if n_ in ("scan", "ogm", "lidar", "waypoints",
+                                                                                     "observe")))
+            dominant = max((k for k in kernels if k != "reset_pass"), key=lambda k: kernels[k]["avg_ms"])
         line = {
             "metric": "aggregate env-steps/s (all agents)",
             "value": env_steps_per_s,
@@ -162,13 +240,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"scenarios/{args.scenario}, {E} batched envs x {N} Laner agents per GPU, "
-                            "waypoints(4x20, lookahead 32)+neighbours(10, r=50 m) obs, dt=0.1, auto-reset "
-                            "(BASELINE.json configs[1])",
+                "workload": f"scenarios/{scenario}, {E} batched envs x {N} Laner agents per GPU, "
+                            "waypoints(4x20, lookahead 32)+neighbours(10, r=50 m) obs"
+                            + (", OGM 64x64 @ 50/64 m/px" if cfg.ogm else "")
+                            + (", lidar 100 rays x 20 m" if cfg.lidar is not None else "")
+                            + f", dt=0.1, auto-reset (BASELINE.json {preset['label']})",
                 "envs_per_gpu": E,
                 "vehicles_per_env": N,
                 "agent_steps_per_s": env_steps_per_s * N,
                 "sharding": f"{world} x ({E} envs), no data-path collective; per-tick reward/done all_gather",
+                "obs_build_ms_per_tick": obs_build_ms,
             },
             "roofline": {
                 "bound": "hbm",
@@ -176,10 +257,14 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
-                "kernel": "smx_tick_kernel",
+                "traffic": traffic["bytes_per_step"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "kernel": "smx_step: k_control > k_scan > [k_ogm] > [k_lidar] > k_waypoints > k_observe > reset pass "
+                          "(one launch sequence per tick; duration = HIP events around the sequence on its stream)",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "bytes_per_agent_step": bytes_agent,
+                "dominant_kernel": dominant,
+                "kernels": kernels,
             },
         }
         if not args.no_cpu_baseline and world == 1:

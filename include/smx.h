@@ -280,8 +280,23 @@ int smx_sync(smx_handle h, void* hip_stream);
 /* Device-side timing: while enabled, every smx_step is bracketed by a hipEvent pair recorded on
  * the stream it is launched on (no synchronisation).  smx_read_step_ms waits for the recorded
  * launches, writes their durations (milliseconds, oldest first, at most `max`) and clears the
- * log; *n receives the count.  smx_last_step_ms is the single-launch convenience form. */
-int smx_set_timing(smx_handle h, int enabled);
+ * log; *n receives the count.  smx_last_step_ms is the single-launch convenience form.
+ *
+ * Levels: 0 = off; 1 = one event pair around the whole smx_step (the bench's timed region uses
+ * this); 2 = a boundary event after every kernel of the tick, read back per phase with
+ * smx_read_phase_ms as ms[n][SMX_PHASE_COUNT] (a phase whose sensor is disabled reads ~0). */
+enum {
+  SMX_PHASE_CONTROL = 0, /* controllers + vehicle dynamics (a1-a6)                 */
+  SMX_PHASE_SCAN,        /* road facts + lanepoint seeds (a8, a9 front half)        */
+  SMX_PHASE_OGM,         /* a14 */
+  SMX_PHASE_LIDAR,       /* a15 */
+  SMX_PHASE_WAYPOINTS,   /* a9 */
+  SMX_PHASE_OBSERVE,     /* a7, a10-a13 */
+  SMX_PHASE_RESET,       /* auto-reset pass (parallel_env.py:303-309), all kernels  */
+  SMX_PHASE_COUNT
+};
+int smx_set_timing(smx_handle h, int level);
+int smx_read_phase_ms(smx_handle h, float* ms, int32_t max_steps, int32_t* n);
 int smx_read_step_ms(smx_handle h, float* ms, int32_t max, int32_t* n);
 int smx_last_step_ms(smx_handle h, float* ms);
 const char* smx_last_error(smx_handle h);

@@ -21,6 +21,7 @@ DONE_ON_SHOULDER, DONE_WRONG_WAY, DONE_NOT_MOVING = 8, 16, 32
  EV_REACHED_MAX_EPISODE_STEPS, EV_AGENTS_ALIVE_DONE, EV_COUNT) = range(10)
 EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way", "not_moving", "reached_goal",
                "reached_max_episode_steps", "agents_alive_done"]
+PHASES = ["control", "scan", "ogm", "lidar", "waypoints", "observe", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
                 "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
@@ -89,7 +90,7 @@ class SmxOutputs(C.Structure):
 
 
 EXPORTS = [
-    "smx_create", "smx_load_map", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
+    "smx_create", "smx_load_map", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
 ]
 
@@ -132,6 +133,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_last_step_ms.restype = C.c_int
     lib.smx_read_step_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]
     lib.smx_read_step_ms.restype = C.c_int
+    lib.smx_read_phase_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]
+    lib.smx_read_phase_ms.restype = C.c_int
     lib.smx_set_timing.argtypes = [h, C.c_int]
     lib.smx_set_timing.restype = C.c_int
     lib.smx_set_controller_gains.argtypes = [h, _f64, _f64]

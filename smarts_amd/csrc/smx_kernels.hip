@@ -1203,6 +1203,9 @@ struct smx_handle_s {
   bool timing;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2*i] start, [2*i+1] stop
   size_t ev_used;                   // pairs recorded since the last read
+  bool phase_timing;
+  std::vector<hipEvent_t> ph_pool;  // SMX_PHASE_COUNT + 1 boundary events per step
+  size_t ph_used;
   std::string err;
 };
 
@@ -1272,6 +1275,8 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->lateral_gain_pos = 3.4;
   h->timing = false;
   h->ev_used = 0;
+  h->phase_timing = false;
+  h->ph_used = 0;
   {
     const char* dbg = getenv("SMX_DEBUG_SKIP");
     h->debug_skip = dbg ? atoi(dbg) : 0;
@@ -1482,14 +1487,35 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     }
     SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used], stream));
   }
+  // phase timing (smx_set_timing level 2): one boundary event after every kernel of the tick
+  const bool phased = h->phase_timing && is_step && h->ph_used < 16384;
+  hipEvent_t* ph = nullptr;
+  if (phased) {
+    const size_t need = (h->ph_used + 1) * (SMX_PHASE_COUNT + 1);
+    while (h->ph_pool.size() < need) {
+      hipEvent_t e;
+      SMX_HIP(hipEventCreate(&e));
+      h->ph_pool.push_back(e);
+    }
+    ph = &h->ph_pool[h->ph_used * (SMX_PHASE_COUNT + 1)];
+    SMX_HIP(hipEventRecord(ph[0], stream));
+  }
+#define SMX_PHASE_END(p) \
+  if (phased) SMX_HIP(hipEventRecord(ph[(p) + 1], stream))
   if (is_step) {
     hipLaunchKernelGGL(k_control, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_CONTROL);
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_SCAN);
     if (c.sensors & SMX_SENSOR_OGM)
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, a);
+    SMX_PHASE_END(SMX_PHASE_OGM);
     if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_LIDAR);
     hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, a);
+    SMX_PHASE_END(SMX_PHASE_WAYPOINTS);
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_OBSERVE);
   }
   if (!is_step || c.auto_reset) {
     KernelArgs r = a;
@@ -1507,6 +1533,11 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
+  if (phased) {
+    SMX_PHASE_END(SMX_PHASE_RESET);
+    h->ph_used += 1;
+  }
+#undef SMX_PHASE_END
   if (timed) {
     SMX_HIP(hipEventRecord(h->ev_pool[2 * h->ev_used + 1], stream));
     h->ev_used += 1;
@@ -1530,9 +1561,29 @@ extern "C" int smx_sync(smx_handle h, void* hip_stream) {
   return SMX_OK;
 }
 
-extern "C" int smx_set_timing(smx_handle h, int enabled) {
+extern "C" int smx_set_timing(smx_handle h, int level) {
   if (!h) return SMX_ERR_INVALID;
-  h->timing = enabled != 0;
+  h->timing = level == 1;
+  h->phase_timing = level == 2;
+  return SMX_OK;
+}
+
+extern "C" int smx_read_phase_ms(smx_handle h, float* ms, int32_t max_steps, int32_t* n) {
+  if (!h || !ms || !n || max_steps < 0) return SMX_ERR_INVALID;
+  int32_t count = 0;
+  for (size_t i = 0; i < h->ph_used; ++i) {
+    hipEvent_t* ph = &h->ph_pool[i * (SMX_PHASE_COUNT + 1)];
+    SMX_HIP(hipEventSynchronize(ph[SMX_PHASE_COUNT]));
+    if (count >= max_steps) continue;
+    for (int p = 0; p < SMX_PHASE_COUNT; ++p) {
+      float t = 0.f;
+      SMX_HIP(hipEventElapsedTime(&t, ph[p], ph[p + 1]));
+      ms[(size_t)count * SMX_PHASE_COUNT + p] = t;
+    }
+    ++count;
+  }
+  h->ph_used = 0;
+  *n = count;
   return SMX_OK;
 }
 
@@ -1565,5 +1616,6 @@ extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ph_pool) (void)hipEventDestroy(e);
   delete h;
 }

@@ -304,6 +304,30 @@ class BatchedSim:
     def state_bytes_per_agent_step(self) -> int:
         return nat.S_COUNT * 8 + 4 + 4 + nat.SEED_COUNT * 4
 
+    def kernel_bytes_per_agent_step(self) -> Dict[str, int]:
+        """Algorithmic HBM bytes of one agent-step, attributed to the kernel that must move them
+        (DESIGN.md "Kernels"): compulsory reads of per-vehicle state/action plus every output byte,
+        map tables (L2/LDS resident) not counted — SURVEY.md §8(d)'s accounting on this layout."""
+        o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items() if k != "env_done"}
+        seeds, facts = nat.SEED_COUNT * 4, nat.FACT_I_COUNT * 4 + nat.FACT_F_COUNT * 8
+        state = nat.S_COUNT * 8 + 4 + 4
+        kb = {
+            # state read + write, action, last tick's seeds
+            "control": 2 * state + 1 + seeds,
+            # pose read, facts + seeds written
+            "scan": 3 * 8 + 4 + facts + seeds,
+            # pose + seeds read, waypoint rows written
+            "waypoints": (3 * 8 + 4 + seeds + sum(v for k, v in o.items() if k.startswith("wp_"))) if self.cfg.waypoints else 0,
+            # state + facts read, trip/accelerometer state written back, ego/neighbour/event/reward rows written
+            "observe": state + facts + 12 * 8 + sum(
+                v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar"))),
+        }
+        if self.cfg.ogm:
+            kb["ogm"] = 3 * 8 + 4 + o["ogm"]
+        if self.cfg.lidar is not None:
+            kb["lidar"] = 3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]
+        return kb
+
     def reset(self, env_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         mask_ptr = None
         if env_mask is not None:
@@ -327,8 +351,18 @@ class BatchedSim:
         nat.check(self.lib, self.handle, rc, "smx_step")
         return self.out
 
-    def set_timing(self, enabled: bool):
-        nat.check(self.lib, self.handle, self.lib.smx_set_timing(self.handle, 1 if enabled else 0), "smx_set_timing")
+    def set_timing(self, level):
+        """0/False = off, 1/True = one event pair per smx_step, 2 = per-kernel phases."""
+        nat.check(self.lib, self.handle, self.lib.smx_set_timing(self.handle, int(level)), "smx_set_timing")
+
+    def read_phase_ms(self, max_steps: int = 16384) -> np.ndarray:
+        """[steps, len(PHASES)] kernel-phase durations (ms) recorded at timing level 2."""
+        k = len(nat.PHASES)
+        buf = (C.c_float * (max_steps * k))()
+        n = C.c_int32()
+        rc = self.lib.smx_read_phase_ms(self.handle, buf, max_steps, C.byref(n))
+        nat.check(self.lib, self.handle, rc, "smx_read_phase_ms")
+        return np.frombuffer(buf, dtype=np.float32, count=n.value * k).reshape(n.value, k).copy()
 
     def last_step_ms(self) -> float:
         ms = C.c_float()

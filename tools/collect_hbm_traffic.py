@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass on gfx950,
+MI355X_MICROARCH.md "rocprofv3 PMC slots") of ``bench.py`` into profiles/<round>_hbm_traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
+    python tools/collect_hbm_traffic.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write \
+        --workload-key c2:loop:1024x8 --out profiles/r01_hbm_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md §HBM): both counters are reported in KiB; WRITE_SIZE is
+exact for wide streaming stores; FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads,
+so the guide's correction doubles it.  The per-step figure divides the totals of this library's
+kernels by the number of k_control dispatches (= smx_step calls).
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+
+def read_counters(directory, counter):
+    per_kernel = defaultdict(float)
+    dispatches = defaultdict(int)
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no *counter_collection.csv under {directory}")
+    for path in files:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0]
+                per_kernel[name] += float(row["Counter_Value"])
+                dispatches[name] += 1
+    return per_kernel, dispatches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--workload-key", required=True)
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    fetch, fd = read_counters(args.fetch, "FETCH_SIZE")
+    write, wd = read_counters(args.write, "WRITE_SIZE")
+    ours = [k for k in set(fetch) | set(write) if k.startswith("k_")]
+    steps_f = fd.get("k_control", 0)
+    steps_w = wd.get("k_control", 0)
+    if not steps_f or not steps_w:
+        raise SystemExit("k_control not found in the counter files")
+    kernels = {}
+    tot_r = tot_w = 0.0
+    for k in sorted(ours):
+        r = fetch.get(k, 0.0) * 1024.0 / steps_f
+        w = write.get(k, 0.0) * 1024.0 / steps_w
+        kernels[k] = {"fetch_bytes_per_step_raw": r, "fetch_bytes_per_step_x2": 2 * r, "write_bytes_per_step": w,
+                      "dispatches_per_step": fd.get(k, 0) / steps_f}
+        tot_r += r
+        tot_w += w
+    rec = {
+        "workload_key": args.workload_key,
+        "steps_profiled": {"fetch_pass": steps_f, "write_pass": steps_w},
+        "read_bytes_per_step_raw": tot_r,
+        "read_bytes_per_step": 2 * tot_r,
+        "write_bytes_per_step": tot_w,
+        "bytes_per_step": 2 * tot_r + tot_w,
+        "kernels": kernels,
+        "source": f"{os.path.basename(args.out)}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "
+                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (upper bound: the doubling is calibrated for wide "
+                  "coalesced reads only)",
+    }
+    with open(args.out, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps({k: rec[k] for k in ("read_bytes_per_step", "write_bytes_per_step", "bytes_per_step")}))
+
+
+if __name__ == "__main__":
+    main()
