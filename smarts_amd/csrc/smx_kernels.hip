@@ -284,21 +284,26 @@ __device__ inline double lane_heading_at_point(const MapDev& m, int lane, double
 
 
 // =================================================================================
-// k_control: controllers + physics, one thread per vehicle
+// k_control: controllers (a1-a3) + vehicle dynamics (a4-a6), SMX_WP_LANES lanes per vehicle.
+// The controller's waypoint query (lane_following_controller.py:96-98) is the long part: the team
+// walks the candidate paths together — lane p synthesises path p, every lane measures the first
+// waypoint of the paths it owns (find_current_lane :367-374) — then the wanted path moves to
+// lane 0 through shuffles and lane 0 runs the control law and the 24 physics substeps.
 // =================================================================================
+__device__ __forceinline__ double team4_get(double v, int src) { return __shfl(v, src, SMX_WP_LANES); }
+
 __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
   int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
-  if (gid >= total) return;
+  const int p0 = threadIdx.x % SMX_WP_LANES;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
+  if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   VehState s = load_vehicle(a, gid, total);
-  SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
-  SF(SMX_S_PREV_Y) = s.y;
   CtrlState cs;
   cs.lat_int = SF(SMX_S_LAT_INT);
   cs.spd_int = SF(SMX_S_SPD_INT);
@@ -310,20 +315,103 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
   const int action = a.actions[gid];
   ControlOut co;
-  if (action >= 0 && !(a.debug_skip & 1)) {
+  // no action this tick: wheel torques do not persist, the steer motor target does
+  co.throttle = 0.0;
+  co.brake = 0.0;
+  co.steering = cs.steer;
+  if (action >= 0 && !(a.debug_skip & 1)) {  // uniform within a team
     // Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
-    double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
-    int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
-    double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
-    double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+    const double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
+    const int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
+    const double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
+    const double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
     const PathSeeds seed = load_seeds(a, gid, total);  // found by k_scan at this very pose
-    co = lane_following_control(m, s, cs, c.dt, target_speed, lane_change, hg, lg, seed, knots, SMX_BLOCK);
-  } else {
-    // no action this tick: wheel torques do not persist, the steer motor target does
-    co.throttle = 0.0;
-    co.brake = 0.0;
-    co.steering = cs.steer;
+    const double px = s.x, py = s.y;
+    CtrlPath path;
+    path.n = 0;
+#pragma unroll
+    for (int k = 0; k < SMX_CTRL_WPS; ++k) path.x[k] = path.y[k] = path.h[k] = 0.0;
+    int n_paths = 0;
+    double my_d = SMX_INF;
+    int my_idx = 0x7fffffff;
+    if (seed.road >= 0) {
+      // paths are numbered in the reference's order: lanes by index, branches depth-first.  Every
+      // lane walks every path (the walk discovers the branchings); lane (idx % 4) owns path idx.
+      for (int li = 0; li < seed.n_lanes; ++li) {
+        const int start = seed_start(m, seed, li, px, py);
+        if (start < 0) continue;
+        BranchState bs;
+        bs.reset();
+        do {
+          const bool mine = (n_paths % SMX_WP_LANES) == p0;
+          if (mine) {
+            double fx = 0.0, fy = 0.0;
+            if (n_paths < SMX_WP_LANES) {
+              path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
+                                           SMX_CTRL_WPS, [&](int i, const WaypointOut& w) {
+                                             ctrl_path_put(path, i, w.x, w.y, w.heading);
+                                             if (i == 0) {
+                                               fx = w.x;
+                                               fy = w.y;
+                                             }
+                                           });
+            } else {
+              equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 1,
+                                  [&](int, const WaypointOut& w) {
+                                    fx = w.x;
+                                    fy = w.y;
+                                  });
+            }
+            const double ex = fx - px, ey = fy - py;
+            const double d = sqrt(ex * ex + ey * ey);
+            if (d < my_d) {  // strict: the lowest-numbered path wins ties (np.argmin)
+              my_d = d;
+              my_idx = n_paths;
+            }
+          } else {
+            equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0,
+                                [&](int, const WaypointOut&) {});
+          }
+          ++n_paths;
+        } while (bs.advance());
+      }
+    }
+    // nearest path over the team: smallest distance, then smallest number
+#pragma unroll
+    for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) {
+      const double od = __shfl_xor(my_d, msk, SMX_WP_LANES);
+      const int oi = __shfl_xor(my_idx, msk, SMX_WP_LANES);
+      if (od < my_d || (od == my_d && oi < my_idx)) {
+        my_d = od;
+        my_idx = oi;
+      }
+    }
+    if (n_paths > 0) {  // uniform within a team
+      int want = my_idx + lane_change;
+      want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
+      const int src = want < SMX_WP_LANES ? want : 0;
+      CtrlPath chosen;
+      chosen.n = __shfl(path.n, src, SMX_WP_LANES);
+#pragma unroll
+      for (int k = 0; k < SMX_CTRL_WPS; ++k) {
+        chosen.x[k] = team4_get(path.x[k], src);
+        chosen.y[k] = team4_get(path.y[k], src);
+        chosen.h[k] = team4_get(path.h[k], src);
+      }
+      if (p0 == 0) {
+        if (want >= SMX_WP_LANES) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, chosen);
+        co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, chosen);
+      }
+    } else {
+      // reference asserts "no waypoints found"; keep the last command
+      co.throttle = cs.throttle;
+      co.brake = 0.0;
+      co.steering = cs.steer;
+    }
   }
+  if (p0 != 0) return;
+  SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
+  SF(SMX_S_PREV_Y) = s.y;
   vehicle_step(s, co, c.dt);
   SF(SMX_S_X) = s.x;
   SF(SMX_S_Y) = s.y;
@@ -1503,7 +1591,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
 #define SMX_PHASE_END(p) \
   if (phased) SMX_HIP(hipEventRecord(ph[(p) + 1], stream))
   if (is_step) {
-    hipLaunchKernelGGL(k_control, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_control, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_CONTROL);
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_SCAN);

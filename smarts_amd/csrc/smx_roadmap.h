@@ -341,13 +341,20 @@ struct KnotWalk {
     start = true;
   }
 
+  __device__ __forceinline__ int first_of_run(const MapDev& m, int first) const {
+    return first >= 0 ? first : m.lp_rec[cur_idx].next0;
+  }
+
   // Advance to the next knot.  Returns its lanepoint index (its record is left in `rec`),
   // or -1 when the path has ended.  `last` tells whether it is the path's last lanepoint.
   __device__ inline int next(const MapDev& m, const RouteFilter& f, BranchState& bs, smx_lp_rec& rec, bool& last) {
     if (remaining <= 0 || cur.n_next == 0) return -1;
     int first, knot, hops, first_lane;
     if (cur.n_next == 1) {
-      first = cur.next0;
+      // `first` (= next0 of the record the walk stands on) is only needed when the path ends
+      // inside the interpolated run; it is re-read there (first_of_run) instead of being carried
+      // in the by-value record across the walk.
+      first = -1;
       knot = cur.knot_next;
       hops = cur.knot_hops;
       first_lane = -1;  // same lane as `cur` when interpolated, else the knot's own lane
@@ -405,7 +412,7 @@ struct KnotWalk {
       }
       if (hops == 1) return -1;
       // the knot's lane is closed: the path stops on the interpolated point before it
-      const int fin = chain_at(m, first, hops - 2, consecutive);
+      const int fin = chain_at(m, first_of_run(m, first), hops - 2, consecutive);
       rec = load_lp(m, fin, 42);
       n += hops - 1;
       remaining = 0;
@@ -414,7 +421,7 @@ struct KnotWalk {
       return fin;
     }
     // the path stops inside the interpolated run
-    const int fin = chain_at(m, first, remaining - 1, consecutive);
+    const int fin = chain_at(m, first_of_run(m, first), remaining - 1, consecutive);
 #ifdef SMX_DEBUG_BOUNDS
     if (fin < 0 || fin >= m.n_lanepoints) {
       smx_dbg_aux[0] = first;

@@ -103,135 +103,62 @@ __device__ __forceinline__ double curvature_calculation(const Traj10& t, int off
   return ds / hs;
 }
 
+
+// The chosen waypoint path of the controller (lookahead 16 => at most 17 waypoints), in registers.
+#define SMX_CTRL_WPS 17
+struct CtrlPath {
+  double x[SMX_CTRL_WPS], y[SMX_CTRL_WPS], h[SMX_CTRL_WPS];
+  int n;
+};
+
+// statically indexed stores / loads (dynamic indexing would put the arrays in scratch)
+__device__ __forceinline__ void ctrl_path_put(CtrlPath& p, int i, double x, double y, double h) {
+#pragma unroll
+  for (int k = 0; k < SMX_CTRL_WPS; ++k)
+    if (k == i) {
+      p.x[k] = x;
+      p.y[k] = y;
+      p.h[k] = h;
+    }
+}
+
 struct ControlOut {
   double throttle, brake, steering;
 };
 
-// lane_following_controller.py:63-365.  Lateral gains: place_poles (:376-437) lands outside the
-// clip window for every target speed of the Lane action space, so they are the clip bounds
-// (0.04, 3.4) for target_speed > 0 and the literals (0.01, 0.36) at 0 — verified against scipy in
-// tests/test_host_logic.py.
-__device__ inline ControlOut lane_following_control(const MapDev& m, const VehState& s, CtrlState& cs, double dt,
-                                                    double target_speed, int lane_change,
-                                                    double heading_error_gain, double lateral_error_gain,
-                                                    const PathSeeds& seed, int* knots, int kstride) {
+// lane_following_controller.py:63-365 after the waypoint query: `path` is wp_paths[want] where
+// want = clip(current_lane + lane_change) (:100-103, find_current_lane :367-374).  Lateral gains:
+// place_poles (:376-437) lands outside the clip window for every target speed of the Lane action
+// space, so they are the clip bounds (0.04, 3.4) for target_speed > 0 and the literals
+// (0.01, 0.36) at 0 — verified against scipy in tests/test_host_logic.py.
+__device__ inline ControlOut lane_following_from_path(const VehState& s, CtrlState& cs, double dt, double target_speed,
+                                                      int lane_change, double heading_error_gain,
+                                                      double lateral_error_gain, const CtrlPath& path) {
   const double px = s.x, py = s.y;
   const double speed = vehicle_speed(s);
-  // ---- waypoint paths, lookahead 16, route = the agent's (empty) route (:96-98).  `seed` holds
-  // the start road / route filter / start lanepoints for this pose (computed by the previous
-  // observation, which queried the map at the same pose).
   ControlOut out;
   out.throttle = cs.throttle;
   out.brake = 0.0;
   out.steering = cs.steer;
-  if (seed.road < 0) return out;  // reference asserts "no waypoints found"; keep the last command
-
-  // pass A: the path nearest to the vehicle by its first waypoint (find_current_lane :367-374);
-  // paths are numbered in the reference's order: lanes by index, branches depth-first.
-  int n_paths = 0;
-  int best_path = 0;
-  double best_d = SMX_INF;
-  int lane_first_path[SMX_SEED_LANES + 1] = {0, 0, 0, 0, 0};  // first path number of each seed lane
-  for (int li = 0; li < seed.n_lanes; ++li) {
-#pragma unroll
-    for (int q = 0; q <= SMX_SEED_LANES; ++q)
-      if (q == li) lane_first_path[q] = n_paths;
-    int start = seed_start(m, seed, li, px, py);
-    if (start < 0) continue;
-    BranchState bs;
-    bs.reset();
-    do {
-      double fx = 0.0, fy = 0.0;
-      equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 1, [&](int, const WaypointOut& w) {
-        fx = w.x;
-        fy = w.y;
-      });
-      double ex = fx - px, ey = fy - py;
-      double d = sqrt(ex * ex + ey * ey);
-      if (d < best_d) {
-        best_d = d;
-        best_path = n_paths;
-      }
-      ++n_paths;
-    } while (bs.advance());
-  }
-  if (n_paths == 0) return out;
-  int want = best_path + lane_change;
-  want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
-
-  // pass B: synthesise the chosen path and fold it into the controller's quantities
+  const int wp_n = path.n;
+  if (wp_n <= 0) return out;  // reference asserts "no waypoints found"; keep the last command
   Traj10 tr;
-  tr.n = 0;
-  double ewma_acc[17];  // headings of the chosen path (static indexing only)
-  int wp_n = 0;
-  double wp3x = 0, wp3y = 0, wp3h = 0, wp4x = 0, wp4y = 0, wp4h = 0, wp0h = 0;
-  double lastx = 0, lasty = 0, lasth = 0;
-  {
-    int idx = 0;
-    bool found = false;
-    for (int li = 0; li < seed.n_lanes && !found; ++li) {
-      // skip whole lanes whose paths all come before the wanted one
-      if (li + 1 < seed.n_lanes && li + 1 <= SMX_SEED_LANES) {
-        int next_first = 0;
-#pragma unroll
-        for (int q = 0; q <= SMX_SEED_LANES; ++q)
-          if (q == li + 1) next_first = lane_first_path[q];
-        if (next_first <= want) {
-          idx = next_first;
-          continue;
-        }
-      }
-      int start = seed_start(m, seed, li, px, py);
-      if (start < 0) continue;
-      BranchState bs;
-      bs.reset();
-      do {
-        if (idx == want) {
-          wp_n = equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 17,
-                                     [&](int i, const WaypointOut& w) {
-#pragma unroll
-            for (int k = 0; k < 17; ++k)
-              if (k == i) ewma_acc[k] = w.heading;
-#pragma unroll
-            for (int k = 0; k < 10; ++k)
-              if (k == i) {
-                tr.x[k] = w.x;
-                tr.y[k] = w.y;
-                tr.h[k] = w.heading;
-              }
-            if (i == 0) wp0h = w.heading;
-            if (i == 3) {
-              wp3x = w.x;
-              wp3y = w.y;
-              wp3h = w.heading;
-            }
-            if (i == 4) {
-              wp4x = w.x;
-              wp4y = w.y;
-              wp4h = w.heading;
-            }
-            lastx = w.x;
-            lasty = w.y;
-            lasth = w.heading;
-          });
-          found = true;
-          break;
-        }
-        // not the wanted path: walk it only to discover its branchings
-        equally_spaced_path(m, seed.f, bs, start, 16, px, py, knots, kstride, 0, [&](int, const WaypointOut&) {});
-        ++idx;
-      } while (bs.advance());
-    }
-  }
-  if (wp_n <= 0) return out;
   tr.n = wp_n < 10 ? wp_n : 10;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    tr.x[k] = path.x[k];
+    tr.y[k] = path.y[k];
+    tr.h[k] = path.h[k];
+  }
+  const double wp0h = path.h[0];
+  const double wp4x = path.x[4], wp4y = path.y[4];
 
   // road curviness (:105-118): EWMA over reversed consecutive pairs
   double ewma = 0.0;
 #pragma unroll
   for (int k = 15; k >= 0; --k) {
     if (k + 1 < wp_n) {
-      double rel = heading_relative_to(ewma_acc[k], ewma_acc[k + 1]);
+      double rel = heading_relative_to(path.h[k], path.h[k + 1]);
       ewma = lerp_ref(ewma, fabs(rel) * (180.0 / SMX_PI), 0.03);
     }
   }
@@ -246,21 +173,14 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
   }
   int look_ahead_wp_num = road_curviness > 0.5 ? 3 : 4;
   look_ahead_wp_num = look_ahead_wp_num < wp_n - 1 ? look_ahead_wp_num : wp_n - 1;
-  double lax, lay, lah;
-  if (look_ahead_wp_num == 4) {
-    lax = wp4x;
-    lay = wp4y;
-    lah = wp4h;
-  } else if (look_ahead_wp_num == 3) {
-    lax = wp3x;
-    lay = wp3y;
-    lah = wp3h;
-  } else {
-    // short path: the look-ahead waypoint is the last one
-    lax = lastx;
-    lay = lasty;
-    lah = lasth;
-  }
+  double lax = path.x[0], lay = path.y[0], lah = path.h[0];
+#pragma unroll
+  for (int k = 1; k <= 4; ++k)
+    if (k == look_ahead_wp_num) {
+      lax = path.x[k];
+      lay = path.y[k];
+      lah = path.h[k];
+    }
   double reference_heading = wp0h;
   double ldx = lax - px, ldy = lay - py;
   double look_ahead_dist = sqrt(ldx * ldx + ldy * ldy);
@@ -341,6 +261,34 @@ __device__ inline ControlOut lane_following_control(const MapDev& m, const VehSt
   out.brake = brake_norm;
   out.steering = cs.steer;
   return out;
+}
+
+
+// Serial search (one lane does everything): number the paths in the reference's order (lanes by
+// index, branches depth-first), pick the one nearest by its first waypoint, synthesise
+// wp_paths[clip(nearest + lane_change)].  k_control uses it only when the wanted path is not one of
+// the four its team synthesises in parallel.
+__device__ inline void ctrl_path_serial(const MapDev& m, const PathSeeds& seed, double px, double py, int want,
+                                        int* knots, int kstride, CtrlPath& path) {
+  path.n = 0;
+  int idx = 0;
+  for (int li = 0; li < seed.n_lanes; ++li) {
+    int start = seed_start(m, seed, li, px, py);
+    if (start < 0) continue;
+    BranchState bs;
+    bs.reset();
+    do {
+      if (idx == want) {
+        path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, kstride, SMX_CTRL_WPS,
+                                     [&](int i, const WaypointOut& w) { ctrl_path_put(path, i, w.x, w.y, w.heading); });
+        return;
+      }
+      // not the wanted path: walk it only to discover its branchings
+      equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, kstride, 0,
+                          [&](int, const WaypointOut&) {});
+      ++idx;
+    } while (bs.advance());
+  }
 }
 
 // AckermannChassis.control (chassis.py:678-718) + one SMARTS tick of the body model.
