@@ -21,6 +21,7 @@ DONE_ON_SHOULDER, DONE_WRONG_WAY, DONE_NOT_MOVING = 8, 16, 32
  EV_REACHED_MAX_EPISODE_STEPS, EV_AGENTS_ALIVE_DONE, EV_COUNT) = range(10)
 EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way", "not_moving", "reached_goal",
                "reached_max_episode_steps", "agents_alive_done"]
+EV = {name.upper(): i for i, name in enumerate(EVENT_NAMES)}
 PHASES = ["control", "scan", "ogm", "lidar", "waypoints", "observe", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",

@@ -1,0 +1,172 @@
+"""Shared engine behind ``HiWayEnv`` and ``ParallelEnv``: E identical env instances x N agents on
+one GPU (``BatchedSim``), with the reference's dict-of-agent-id surface on top.
+
+Plays the role of ``SMARTS`` + ``AgentManager`` (reference ``smarts/core/smarts.py:187-227, 365-460``,
+``agent_manager.py:161-240``) for the whole batch.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _native as nat
+from ..lidar import base_rays
+from .agent import AgentSpec
+from .agent_interface import ActionSpaceType, AgentInterface
+from .observations import Observation, ObservationBuilder
+
+# Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
+LANE_ACTIONS = {"keep_lane": 0, "slow_down": 1, "change_lane_left": 2, "change_lane_right": 3}
+NO_ACTION = -1
+
+PKG_SCENARIOS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenarios")
+
+
+class SMARTSNotSetupError(Exception):
+    """smarts.py:73-76: stepping before reset."""
+
+
+class SMARTSDestroyedError(Exception):
+    """smarts.py:79-82: use after destroy."""
+
+
+def resolve_scenario(path: str) -> str:
+    """A scenario directory holding ``map.net.xml`` (the reference's layout, scenario.py:109-121) or
+    the compact ``map.smxnet.json.gz``; a bare reference-style name (``scenarios/loop``) falls back
+    to the maps shipped with the package."""
+    cands = [path]
+    parts = os.path.normpath(path).split(os.sep)
+    if "scenarios" in parts:
+        tail = parts[parts.index("scenarios") + 1:]
+        cands.append(os.path.join(PKG_SCENARIOS, *tail))
+    cands.append(os.path.join(PKG_SCENARIOS, os.path.basename(os.path.normpath(path))))
+    for c in cands:
+        if os.path.isdir(c) and any(os.path.exists(os.path.join(c, f)) for f in ("map.net.xml", "map.smxnet.json.gz")):
+            return c
+    raise FileNotFoundError(f"scenario {path!r}: no map.net.xml / map.smxnet.json.gz found (looked in {cands})")
+
+
+def encode_lane_action(action: Any) -> int:
+    """Lane action string -> device code; anything else is an error, as in the reference
+    (controllers/__init__.py:137-144 looks the string up in a dict)."""
+    if isinstance(action, str):
+        if action not in LANE_ACTIONS:
+            raise KeyError(f"unknown Lane action {action!r}; expected one of {sorted(LANE_ACTIONS)}")
+        return LANE_ACTIONS[action]
+    raise TypeError(f"ActionSpaceType.Lane expects a string action, got {type(action).__name__}")
+
+
+def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: int, dt: float, auto_reset: bool,
+                              waypoint_window: Tuple[int, int] = (4, 20)):
+    """AgentInterface -> SimConfig (one interface for every agent, as FormatObs also requires,
+    format_obs.py:207-210)."""
+    from ..engine import SimConfig
+
+    itf.validate_for_device()
+    dc, evc = itf.done_criteria, itf.event_configuration
+    kw: Dict[str, Any] = dict(
+        num_envs=num_envs, num_vehicles=num_agents, dt=dt,
+        waypoints=bool(itf.waypoints), wp_lookahead=itf.waypoints.lookahead if itf.waypoints else 32,
+        neighbors=bool(itf.neighborhood_vehicles),
+        nb_radius=itf.neighborhood_vehicles.radius if itf.neighborhood_vehicles else None,
+        accelerometer=bool(itf.accelerometer), max_episode_steps=itf.max_episode_steps,
+        done_collision=dc.collision, done_off_road=dc.off_road, done_off_route=dc.off_route,
+        done_on_shoulder=dc.on_shoulder, done_wrong_way=dc.wrong_way, done_not_moving=dc.not_moving,
+        not_moving_time=evc.not_moving_time, not_moving_distance=evc.not_moving_distance, auto_reset=auto_reset,
+    )
+    if itf.waypoints:
+        # the dense rows keep the StdObs window (format_obs.py:42) unless the lookahead is shorter
+        kw["wp_paths"] = waypoint_window[0]
+        kw["wp_len"] = min(waypoint_window[1], itf.waypoints.lookahead + 1)
+    if itf.ogm:
+        kw.update(ogm=True, ogm_width=itf.ogm.width, ogm_height=itf.ogm.height, ogm_resolution=itf.ogm.resolution)
+    if itf.lidar:
+        kw.update(lidar=itf.lidar.sensor_params)
+    return SimConfig(**kw)
+
+
+class BatchCore:
+    """E env instances of one scenario x the agents of ``agent_specs`` on one device."""
+
+    def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
+                 auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20)):
+        from ..engine import BatchedSim, make_spawns
+        from ..map_compiler import compile_map
+        from ..sumo_map import load_net
+
+        self.agent_ids: List[str] = list(agent_specs.keys())
+        self.agent_specs = agent_specs
+        interfaces = [spec.interface for spec in agent_specs.values()]
+        if any(i is None for i in interfaces):
+            raise ValueError("every AgentSpec needs an interface")
+        first = interfaces[0]
+        if any(i != first for i in interfaces[1:]):
+            raise NotImplementedError("all agents of an accelerated env must share one AgentInterface")
+        self.interface: AgentInterface = first
+        self.E, self.N, self.dt, self.seed = num_envs, len(self.agent_ids), dt, seed
+        self.scenario_dir = resolve_scenario(scenario_dir)
+        self.net = load_net(self.scenario_dir)
+        self.cm = compile_map(self.net)
+        self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window)
+        spawns = make_spawns(self.cm, num_envs, self.N, episodes=4, seed=seed)
+        self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed)
+        road_ids = [self.cm.road_ids[r] for r in self.cm.lane_road]
+        self.builder = ObservationBuilder(
+            self.cm.lane_ids, road_ids, self.agent_ids, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
+            accelerometer=self.cfg.accelerometer, ogm=first.ogm or None,
+            lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt)
+        self._was_reset = False
+        self._destroyed = False
+        self.step_count = np.zeros(num_envs, dtype=np.int64)
+
+    # ------------------------------------------------------------------ dense (fast) path
+    def reset_dense(self, env_mask=None):
+        self._check_alive()
+        out = self.sim.reset(env_mask)
+        self._was_reset = True
+        if env_mask is None:
+            self.step_count[:] = self.cfg.reset_elapsed_steps()
+        return out
+
+    def step_dense(self, actions):
+        """``actions``: int8 tensor [E, N] of lane-action codes (NO_ACTION = -1)."""
+        self._check_alive()
+        if not self._was_reset:
+            raise SMARTSNotSetupError("Must call reset() or setup() before stepping.")
+        out = self.sim.step(actions)
+        self.step_count += 1
+        return out
+
+    # ------------------------------------------------------------------ object path
+    def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
+        acts = np.full((self.E, self.N), NO_ACTION, dtype=np.int8)
+        for e, agent_actions in enumerate(per_env_actions):
+            assert isinstance(agent_actions, dict) and all(isinstance(k, str) for k in agent_actions), \
+                "Expected Dict[str, any]"  # hiway_env.py:232-234
+            for agent_id, action in agent_actions.items():
+                spec = self.agent_specs[agent_id]
+                acts[e, self.agent_ids.index(agent_id)] = encode_lane_action(spec.action_adapter(action))
+        return acts
+
+    def host_rows(self, out) -> Dict[str, np.ndarray]:
+        import torch
+
+        torch.cuda.synchronize(self.sim.device)
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+    def observations(self, rows: Dict[str, np.ndarray], env: int, present: np.ndarray) -> Dict[str, Observation]:
+        er = {k: v[env] for k, v in rows.items() if k != "env_done"}
+        t = int(self.step_count[env])
+        elapsed = round(t * self.dt, 6)
+        return {self.agent_ids[i]: self.builder.build(er, i, t, elapsed) for i in range(self.N) if present[i]}
+
+    def close(self):
+        if not self._destroyed:
+            self.sim.close()
+            self._destroyed = True
+
+    def _check_alive(self):
+        if self._destroyed:
+            raise SMARTSDestroyedError("BUG: SMARTS was destroyed and is no longer usable")

@@ -379,6 +379,95 @@ SCENARIOS = {
 }
 
 
+def dump_std_obs():
+    """Reference ``lane_ttc`` (custom_observations.py:148-280) and ``FormatObs._std_*``
+    (format_obs.py:401-603) on observations of an oracle rollout (loop, 1 env x 8 agents,
+    waypoints + neighbours).  The reference objects are filled field by field from the dense rows
+    (tests/parity.pack), which are stored as the fixture's input."""
+    for name in ("gym.envs", "gym.envs.registration", "gym.wrappers"):
+        _stub(name)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import parity
+    from smarts.core.coordinates import Dimensions as RDimensions
+    from smarts.core.coordinates import Heading as RHeading
+    from smarts.core.events import Events as REvents
+    from smarts.core.road_map import Waypoint as RWaypoint
+    from smarts.core.sensors import EgoVehicleObservation as REgo
+    from smarts.core.sensors import Observation as RObservation
+    from smarts.core.sensors import VehicleObservation as RVehicle
+    from smarts.core.sensors import Vias as RVias
+    from smarts.env import custom_observations as rco
+    from smarts.env.wrappers import format_obs as rfo
+
+    from smarts_amd.engine import SimConfig, make_spawns
+    from smarts_amd.env.observations import ObservationBuilder
+    from smarts_amd.map_compiler import compile_map
+    from smarts_amd.sumo_map import load_net
+
+    net = load_net(os.path.join(REPO, "smarts_amd", "scenarios", "loop"))
+    cm = compile_map(net)
+    E, N = 1, 8
+    cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0)
+    spawns = make_spawns(cm, E, N, episodes=1, seed=7)
+    ob = parity.OracleBatch(net, cm, cfg, spawns[0])
+    agent_ids = [f"agent_{i}" for i in range(N)]
+    builder = ObservationBuilder(cm.lane_ids, [cm.road_ids[r] for r in cm.lane_road], agent_ids, waypoints=True,
+                                 neighbors=True, accelerometer=True, dt=0.1)
+
+    def to_ref(o):
+        e = o.ego_vehicle_state
+        ego = REgo(id=e.id, position=e.position, bounding_box=RDimensions(*e.bounding_box.as_lwh),
+                   heading=RHeading(float(e.heading)), speed=e.speed, steering=e.steering, yaw_rate=e.yaw_rate,
+                   road_id=e.road_id, lane_id=e.lane_id, lane_index=e.lane_index, mission=None,
+                   linear_velocity=e.linear_velocity, angular_velocity=e.angular_velocity,
+                   linear_acceleration=e.linear_acceleration, angular_acceleration=e.angular_acceleration,
+                   linear_jerk=e.linear_jerk, angular_jerk=e.angular_jerk)
+        nbs = [RVehicle(id=v.id, position=v.position, bounding_box=RDimensions(*v.bounding_box.as_lwh),
+                        heading=RHeading(float(v.heading)), speed=v.speed, road_id=v.road_id, lane_id=v.lane_id,
+                        lane_index=v.lane_index) for v in o.neighborhood_vehicle_states]
+        paths = [[RWaypoint(pos=w.pos, heading=RHeading(float(w.heading)), lane_id=w.lane_id, lane_width=w.lane_width,
+                            speed_limit=w.speed_limit, lane_index=w.lane_index) for w in p] for p in o.waypoint_paths]
+        ev = REvents(**o.events._asdict())
+        return RObservation(dt=o.dt, step_count=o.step_count, elapsed_sim_time=o.elapsed_sim_time, events=ev,
+                            ego_vehicle_state=ego, neighborhood_vehicle_states=nbs, waypoint_paths=paths,
+                            distance_travelled=o.distance_travelled, lidar_point_cloud=None,
+                            drivable_area_grid_map=None, occupancy_grid_map=None, top_down_rgb=None,
+                            road_waypoints=None, via_data=RVias(near_via_points=[], hit_via_points=[]))
+
+    rng = np.random.default_rng(7)
+    out = {}
+    rows = ob.reset_observe()
+    tick = 0
+    for t in range(12):
+        acts = np.where(rng.random((E, N)) < 0.6, 0, rng.integers(1, 4, (E, N))).astype(np.int8)
+        rows = ob.step(acts)
+        if t % 4 != 3:
+            continue
+        for k, v in rows.items():
+            out[f"t{tick}_in_{k}"] = v
+        for i in range(N):
+            if not rows["active"][i]:
+                continue
+            ro = to_ref(builder.build(rows, i, t + 2, round((t + 2) * 0.1, 6)))
+            ttc = rco.lane_ttc(ro)
+            for k, v in ttc.items():
+                out[f"t{tick}_a{i}_lanettc_{k}"] = np.asarray(v, dtype=np.float64)
+            wp = rfo._std_waypoints(ro.waypoint_paths)
+            for k, v in wp.items():
+                out[f"t{tick}_a{i}_wp_{k}"] = v
+            nb = rfo._std_neighbors(ro.neighborhood_vehicle_states)
+            for k, v in (nb or {}).items():
+                out[f"t{tick}_a{i}_nb_{k}"] = v
+            sttc = rfo._std_ttc(ro)
+            for k, v in (sttc or {}).items():
+                out[f"t{tick}_a{i}_ttc_{k}"] = np.asarray(v)
+            for k, v in rfo._std_ego(ro.ego_vehicle_state).items():
+                out[f"t{tick}_a{i}_ego_{k}"] = np.asarray(v)
+        tick += 1
+    out["n_ticks"] = np.array(tick)
+    return out
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -387,7 +476,10 @@ def main():
     if os.environ.get("GOLDEN_ONLY", "") in ("", "lidar"):
         np.savez_compressed(os.path.join(OUT, "lidar_rays.npz"), **dump_lidar_rays())
         print("lidar rays written")
-    if os.environ.get("GOLDEN_ONLY", "") == "lidar":
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "stdobs"):
+        np.savez_compressed(os.path.join(OUT, "std_obs.npz"), **dump_std_obs())
+        print("std obs written")
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))
