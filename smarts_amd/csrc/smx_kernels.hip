@@ -56,9 +56,9 @@ struct KernelArgs {
 // ---------------------------------------------------------------------------------
 // oriented-box proximity (substitution for pybullet getClosestPoints)
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void box_corners(double x, double y, double h, double len, double wid, double* cx,
-                                            double* cy) {
-  double fx = -sin(h), fy = cos(h), rx = cos(h), ry = sin(h);
+__device__ __forceinline__ void box_corners(double x, double y, double sh, double ch, double len, double wid,
+                                            double* cx, double* cy) {
+  double fx = -sh, fy = ch, rx = ch, ry = sh;
   double hl = 0.5 * len, hw = 0.5 * wid;
   cx[0] = x + fx * hl + rx * hw;
   cy[0] = y + fy * hl + ry * hw;
@@ -70,9 +70,9 @@ __device__ __forceinline__ void box_corners(double x, double y, double h, double
   cy[3] = y - fy * hl + ry * hw;
 }
 
-__device__ __forceinline__ bool point_in_box(double px, double py, double x, double y, double h, double len,
-                                             double wid) {
-  double fx = -sin(h), fy = cos(h), rx = cos(h), ry = sin(h);
+__device__ __forceinline__ bool point_in_box(double px, double py, double x, double y, double sh, double ch,
+                                             double len, double wid) {
+  double fx = -sh, fy = ch, rx = ch, ry = sh;
   double dx = px - x, dy = py - y;
   return fabs(dx * fx + dy * fy) <= 0.5 * len && fabs(dx * rx + dy * ry) <= 0.5 * wid;
 }
@@ -93,19 +93,22 @@ __device__ inline bool boxes_within(double ax, double ay, double ah, double bx, 
   double reach = sqrt(len * len + wid * wid) + leeway;
   if (dx * dx + dy * dy > reach * reach) return false;
   double cax[4], cay[4], cbx[4], cby[4];
-  box_corners(ax, ay, ah, len, wid, cax, cay);
-  box_corners(bx, by, bh, len, wid, cbx, cby);
+  double sa, ca, sb, cb;
+  sincos(ah, &sa, &ca);
+  sincos(bh, &sb, &cb);
+  box_corners(ax, ay, sa, ca, len, wid, cax, cay);
+  box_corners(bx, by, sb, cb, len, wid, cbx, cby);
   double best = SMX_INF;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (point_in_box(cax[i], cay[i], bx, by, bh, len, wid)) return true;
+    if (point_in_box(cax[i], cay[i], bx, by, sb, cb, len, wid)) return true;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       best = fmin(best, seg_point_dist2(cax[i], cay[i], cbx[k], cby[k], cbx[(k + 1) & 3], cby[(k + 1) & 3]));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (point_in_box(cbx[i], cby[i], ax, ay, ah, len, wid)) return true;
+    if (point_in_box(cbx[i], cby[i], ax, ay, sa, ca, len, wid)) return true;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       best = fmin(best, seg_point_dist2(cbx[i], cby[i], cax[k], cay[k], cax[(k + 1) & 3], cay[(k + 1) & 3]));
@@ -823,7 +826,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
       my_lane_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
     }
   }
-  const double speed = vehicle_speed(s);
+  const HeadingTrig trig = heading_trig(s.heading);
+  const double speed = vehicle_speed(s, trig);
   {
     SharedPose& p = pose[local];
     p.x = s.x;
@@ -848,18 +852,32 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
     // ---- collisions (smarts.py:1270-1291): a new vehicle has not been through a physics step
     bool collided = false;
     if (!first && !(a.debug_skip & 4)) {
+      // broad phase over all env-mates first (circumscribed circles), narrow phase only over the
+      // survivors: a wavefront then pays for max-over-lanes(candidates) box tests, not for n_veh
+      unsigned long long cand = 0ull;
+      const double reach = sqrt(SMX_CHASSIS_LENGTH * SMX_CHASSIS_LENGTH + SMX_CHASSIS_WIDTH * SMX_CHASSIS_WIDTH) +
+                           SMX_COLLISION_LEEWAY;
       for (int j = 0; j < n_veh; ++j) {
         if (j == slot) continue;
         const SharedPose& q = env_pose[j];
         if (!q.alive) continue;
-        if (boxes_within(px, py, wrap_heading(s.heading), q.x, q.y, q.heading, SMX_CHASSIS_LENGTH, SMX_CHASSIS_WIDTH,
+        const double dx = px - q.x, dy = py - q.y;
+        if (dx * dx + dy * dy > reach * reach) continue;
+        cand |= 1ull << j;
+      }
+      const double my_h = wrap_heading(s.heading);
+      while (cand != 0ull && !collided) {
+        const int j = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        const SharedPose& q = env_pose[j];
+        if (boxes_within(px, py, my_h, q.x, q.y, q.heading, SMX_CHASSIS_LENGTH, SMX_CHASSIS_WIDTH,
                          SMX_COLLISION_LEEWAY))
           collided = true;
       }
     }
 
     double lng, lat;
-    long_lat_speed(s, lng, lat);
+    long_lat_speed(s, trig, lng, lat);
     // ---- ego lane (sensors.py:277-285): nearest lane within max(10, 2 * default lane width)
     const int ego_lane = (my_lane >= 0 && my_lane_dist < fmax(10.0, 2.0 * m.default_lane_width)) ? my_lane : -1;
     // ---- ego vehicle state (sensors.py:314-329; read-back of chassis.py:493-566)
@@ -1140,18 +1158,36 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
   const int n_veh = c.num_vehicles;
   const int env = (int)(gid / n_veh);
   const int slot = (int)(gid - (size_t)env * n_veh);
-  if (threadIdx.x < n_veh) {
-    const size_t og = (size_t)env * n_veh + threadIdx.x;
+  // env-mates that a ray can reach at all (|ray| = max_distance; a chassis box lies within 2.1 m of
+  // its centre), compacted into LDS by ballot / prefix count — the order does not matter for a min
+  __shared__ int n_mates;
+  {
+    const double ex = SF(SMX_S_X), ey = SF(SMX_S_Y);
+    const double reach = c.lidar_max_distance + 2.1;
+    bool keep = false;
     LidarPose p;
-    p.x = a.st.f64[(size_t)SMX_S_X * total + og];
-    p.y = a.st.f64[(size_t)SMX_S_Y * total + og];
-    const double h = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
-    p.fx = -sin(h);
-    p.fy = cos(h);
-    p.alive = (a.st.flags[og] & SMX_F_ALIVE) ? 1 : 0;
-    mates[threadIdx.x] = p;
+    p.x = p.y = p.fx = p.fy = 0.0;
+    p.alive = 1;
+    if ((int)threadIdx.x < n_veh && (int)threadIdx.x != slot) {
+      const size_t og = (size_t)env * n_veh + threadIdx.x;
+      if (a.st.flags[og] & SMX_F_ALIVE) {
+        p.x = a.st.f64[(size_t)SMX_S_X * total + og];
+        p.y = a.st.f64[(size_t)SMX_S_Y * total + og];
+        const double dx = p.x - ex, dy = p.y - ey;
+        if (dx * dx + dy * dy <= reach * reach) {
+          const double h = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
+          p.fx = -sin(h);
+          p.fy = cos(h);
+          keep = true;
+        }
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (keep) mates[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = p;
+    if (threadIdx.x == 0) n_mates = __popcll(mask);
   }
   __syncthreads();
+  const int mates_n = n_mates;
   const double ox = SF(SMX_S_X), oy = SF(SMX_S_Y), oz = SMX_BASE_HEIGHT + 1.0;
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH, hh = 0.5 * SMX_CHASSIS_HEIGHT;
   const double bz = SMX_BASE_HEIGHT + 0.6;  // chassis box centre height (models/vehicle.urdf)
@@ -1162,10 +1198,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
       const double t = -oz / dz;
       if (t >= 0.0 && t <= 1.0) best = t;
     }
-    for (int j = 0; j < n_veh; ++j) {
-      if (j == slot) continue;
+    for (int j = 0; j < mates_n; ++j) {
       const LidarPose p = mates[j];
-      if (!p.alive) continue;
       const double relx = ox - p.x, rely = oy - p.y, relz = oz - bz;
       // slabs along the box axes: forward f, right r = (f.y, -f.x), up
       double tmin = 0.0, tmax = 1.0;

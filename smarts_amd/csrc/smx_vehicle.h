@@ -44,25 +44,33 @@ struct CtrlState {
   bool mcl_set;
 };
 
+// sin / cos of the heading, evaluated once per use site
+struct HeadingTrig {
+  double sh, ch;
+};
+__device__ __forceinline__ HeadingTrig heading_trig(double heading) {
+  HeadingTrig t;
+  sincos(heading, &t.sh, &t.ch);
+  return t;
+}
+
 // chassis.py:558-566 (body-frame speeds recovered from the world velocity, as the reference does)
-__device__ __forceinline__ void world_velocity(const VehState& s, double& vx, double& vy) {
-  double sh = sin(s.heading), ch = cos(s.heading);
+__device__ __forceinline__ void world_velocity(const VehState& s, const HeadingTrig& t, double& vx, double& vy) {
   // forward = (-sin h, cos h); left = (-cos h, -sin h)
-  vx = s.u * (-sh) + s.v * (-ch);
-  vy = s.u * ch + s.v * (-sh);
+  vx = s.u * (-t.sh) + s.v * (-t.ch);
+  vy = s.u * t.ch + s.v * (-t.sh);
 }
 
-__device__ __forceinline__ void long_lat_speed(const VehState& s, double& lng, double& lat) {
+__device__ __forceinline__ void long_lat_speed(const VehState& s, const HeadingTrig& t, double& lng, double& lat) {
   double vx, vy;
-  world_velocity(s, vx, vy);
-  double sh = sin(s.heading), ch = cos(s.heading);
-  lng = vy * ch - vx * sh;
-  lat = vy * sh + vx * ch;
+  world_velocity(s, t, vx, vy);
+  lng = vy * t.ch - vx * t.sh;
+  lat = vy * t.sh + vx * t.ch;
 }
 
-__device__ __forceinline__ double vehicle_speed(const VehState& s) {
+__device__ __forceinline__ double vehicle_speed(const VehState& s, const HeadingTrig& t) {
   double vx, vy;
-  world_velocity(s, vx, vy);
+  world_velocity(s, t, vx, vy);
   return sqrt(vx * vx + vy * vy + 0.0 * 0.0);
 }
 
@@ -135,7 +143,8 @@ __device__ inline ControlOut lane_following_from_path(const VehState& s, CtrlSta
                                                       int lane_change, double heading_error_gain,
                                                       double lateral_error_gain, const CtrlPath& path) {
   const double px = s.x, py = s.y;
-  const double speed = vehicle_speed(s);
+  const HeadingTrig trig = heading_trig(s.heading);
+  const double speed = vehicle_speed(s, trig);
   ControlOut out;
   out.throttle = cs.throttle;
   out.brake = 0.0;
@@ -184,8 +193,8 @@ __device__ inline ControlOut lane_following_from_path(const VehState& s, CtrlSta
   double reference_heading = wp0h;
   double ldx = lax - px, ldy = lay - py;
   double look_ahead_dist = sqrt(ldx * ldx + ldy * ldy);
-  double vlx = px - look_ahead_dist * sin(s.heading);
-  double vly = py + look_ahead_dist * cos(s.heading);
+  double vlx = px - look_ahead_dist * trig.sh;
+  double vly = py + look_ahead_dist * trig.ch;
 
   double raw_throttle;
   if (road_curviness < 0.3) {
@@ -216,7 +225,7 @@ __device__ inline ControlOut lane_following_from_path(const VehState& s, CtrlSta
   double curvature_radius = curvature_calculation(tr, 0);
   double brake_norm = 0.0, throttle_norm;
   double lng, lat;
-  long_lat_speed(s, lng, lat);
+  long_lat_speed(s, trig, lng, lat);
   if (raw_throttle < 0.0) {
     brake_norm = clip_ref(-raw_throttle, 0.0, 1.0);
     throttle_norm = 0.0;
@@ -292,9 +301,17 @@ __device__ inline void ctrl_path_serial(const MapDev& m, const PathSeeds& seed, 
 }
 
 // AckermannChassis.control (chassis.py:678-718) + one SMARTS tick of the body model.
+// The heading's sine / cosine are carried from substep to substep by rotating them through the
+// substep's yaw increment d = h * r (|d| <= a few mrad; sin d / cos d from their Taylor series to
+// d^7 / d^8, truncation < 1e-20): 24 libm sincos calls become one, with < 1e-14 drift per tick.
 __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
+  double sh, ch;
+  sincos(s.heading, &sh, &ch);
+  HeadingTrig t0;
+  t0.sh = sh;
+  t0.ch = ch;
   double lng, lat;
-  long_lat_speed(s, lng, lat);
+  long_lat_speed(s, t0, lng, lat);
   double brake = c.brake;
   if (brake > 0.0 && lng < 1.0 / 36.0) brake = 0.0;
   int substeps = (int)(dt * SMX_MAX_PYBULLET_FREQ);
@@ -322,12 +339,21 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
       r_new = u_new * tan(s.delta) / SMX_WHEELBASE;
       v_new = r_new * SMX_AXLE_DIST;
     }
-    double hd = s.heading;
-    double sh, ch;
-    sincos(hd, &sh, &ch);
+    const double hd = s.heading;
     s.x += h * (-u_new * sh - v_new * ch);
     s.y += h * (u_new * ch - v_new * sh);
-    s.heading = hd + h * r_new;
+    const double d = h * r_new;
+    s.heading = hd + d;
+    if (fabs(d) < 0.05) {
+      const double d2 = d * d;
+      const double sd = d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0))));
+      const double cd = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0))));
+      const double nsh = sh * cd + ch * sd;
+      ch = ch * cd - sh * sd;
+      sh = nsh;
+    } else {
+      sincos(s.heading, &sh, &ch);
+    }
     s.u = u_new;
     s.v = v_new;
     s.r = r_new;
