@@ -123,6 +123,11 @@ typedef struct smx_succ_rec { /* one entry of LinkedLanePoint.nexts */
   int32_t knot;               /* first non-inferred lanepoint down that branch */
   int32_t hops;               /* hops from the branching point to it */
 } smx_succ_rec;
+typedef struct smx_shape_rec { /* one centre-line vertex of a lane (Lane shape, sumo_road_network.py:287-296) */
+  double x, y;
+  double cum;                 /* arclength from the lane's first vertex, summed vertex by vertex */
+  double len;                 /* length of the segment to the next vertex (0 on the last one)   */
+} smx_shape_rec;
 typedef struct smx_pt_rec { double x, y; int32_t idx, lane; } smx_pt_rec;   /* lanepoint grid member */
 typedef struct smx_seg_rec {  /* centre-line segment grid member */
   double x1, y1, x2, y2;
@@ -143,6 +148,7 @@ typedef struct smx_map_tables {
   const int32_t* lane_shape_off; /* n_lanes + 1 */
   const double* shape_x;
   const double* shape_y;
+  const smx_shape_rec* shape_rec; /* n_shape_pts, same order as shape_x / shape_y */
   const int32_t* lane_out_off;   /* n_lanes + 1 */
   const int32_t* lane_out_idx;   /* Lane.outgoing_lanes (sumo_road_network.py:350-358) */
   const int32_t* road_lane_off;  /* n_roads + 1 */
@@ -201,12 +207,12 @@ typedef struct smx_state {
                           (lane_following_controller.py:96-98) and reuses them     */
   int32_t* facts_i32;  /* [SMX_FACT_I_COUNT][E*N] per-tick map facts of each vehicle (scan kernel
                           -> observe kernels): nearest lane, road flags, trip-meter seed   */
-  double* facts_f64;   /* [SMX_FACT_F_COUNT][E*N]: nearest-lane distance                     */
+  double* facts_f64;   /* [SMX_FACT_F_COUNT][E*N]: nearest-lane distance, lane heading there  */
   int32_t* env_reset_pending; /* [E] set by the observe kernel when auto_reset fires        */
 } smx_state;
 #define SMX_SEED_COUNT 9 /* road, filter n, filter roads x2, lane count, start lanepoint x4 */
 enum { SMX_FI_LANE = 0, SMX_FI_FLAGS, SMX_FI_TRIP_START, SMX_FI_OBS_START, SMX_FACT_I_COUNT };
-enum { SMX_FF_LANE_DIST = 0, SMX_FACT_F_COUNT };
+enum { SMX_FF_LANE_DIST = 0, SMX_FF_LANE_HEADING /* lane heading at the nearest centre-line point */, SMX_FACT_F_COUNT };
 enum { SMX_FACT_ON_ROAD = 1 << 0, SMX_FACT_CORNER_SHIFT = 1 /* bits 1-4: corner q on road */ };
 
 /* Spawn table: episode k of env e starts from row (k mod episodes).

@@ -30,7 +30,7 @@ STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT
 S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
 F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST = 1, 2, 4, 3, 32
-FACT_I_COUNT, FACT_F_COUNT = 4, 1
+FACT_I_COUNT, FACT_F_COUNT = 4, 2
 DRIVEN_PATH_LEN = 500
 SEED_COUNT = 9
 EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,
@@ -57,7 +57,7 @@ class SmxMapTables(C.Structure):
     _fields_ = [
         ("n_lanes", _i32), ("n_roads", _i32), ("n_lanepoints", _i32), ("n_shape_pts", _i32), ("n_succ", _i32),
         ("lane_road", _p), ("lane_index", _p), ("lane_width", _p), ("lane_speed", _p), ("lane_length", _p),
-        ("lane_in_junction", _p), ("lane_shape_off", _p), ("shape_x", _p), ("shape_y", _p),
+        ("lane_in_junction", _p), ("lane_shape_off", _p), ("shape_x", _p), ("shape_y", _p), ("shape_rec", _p),
         ("lane_out_off", _p), ("lane_out_idx", _p), ("road_lane_off", _p), ("road_lanes", _p),
         ("road_is_junction", _p), ("road_out_road", _p),
         ("lp_rec", _p), ("succ_rec", _p),

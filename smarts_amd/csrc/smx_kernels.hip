@@ -170,122 +170,6 @@ __device__ __forceinline__ VehState load_vehicle(const KernelArgs& a, size_t gid
   s.delta = SF(SMX_S_DELTA);
   return s;
 }
-// ---------------------------------------------------------------------------------
-// lane heading at the centre-line point closest to (px, py):
-//   Lane.center_pose_at_point(point).heading  (road_map.py:390-396)
-//   = offset_along_lane (sumo_road_network.py:476-491, math.py:370-390)
-//   + vector_at_offset (road_map.py:377-388) over from_lane_coord (math.py:333-345)
-//   + Pose(fast_quaternion_from_angle(vec_to_radians(v))).heading (coordinates.py:394-403)
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ bool is_close_ref(double a, double b) {
-  return fabs(a - b) <= fmax(1e-09 * fmax(fabs(a), fabs(b)), 0.0);
-}
-
-__device__ __forceinline__ void position_at_offset(double x1, double y1, double x2, double y2, double offset,
-                                                   double& ox, double& oy) {
-  if (is_close_ref(offset, 0.0)) {
-    ox = x1;
-    oy = y1;
-    return;
-  }
-  double dist = euclid(x1, y1, x2, y2);
-  if (is_close_ref(dist, offset)) {
-    ox = x2;
-    oy = y2;
-    return;
-  }
-  ox = x1 + (x2 - x1) * (offset / dist);
-  oy = y1 + (y2 - y1) * (offset / dist);
-}
-
-__device__ inline void position_at_shape_offset(const MapDev& m, int v0, int v1, double offset, double& ox,
-                                                double& oy) {
-  double seen_length = 0.0;
-  double cx = m.shape_x[v0], cy = m.shape_y[v0];
-  for (int v = v0 + 1; v < v1; ++v) {
-    double nx = m.shape_x[v], ny = m.shape_y[v];
-    double next_length = euclid(cx, cy, nx, ny);
-    if (seen_length + next_length > offset) {
-      position_at_offset(cx, cy, nx, ny, offset - seen_length, ox, oy);
-      return;
-    }
-    seen_length += next_length;
-    cx = nx;
-    cy = ny;
-  }
-  ox = m.shape_x[v1 - 1];
-  oy = m.shape_y[v1 - 1];
-}
-
-__device__ inline double lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
-  const int v0 = m.lane_shape_off[SMX_BCHK(31, lane, m.n_lanes)], v1 = m.lane_shape_off[lane + 1];
-  // offset_along_lane
-  double offset;
-  {
-    bool on_vertex = false;
-    double acc = 0.0, vertex_offset = 0.0;
-    for (int v = v0; v < v1; ++v) {
-      if (m.shape_x[v] == px && m.shape_y[v] == py) {
-        on_vertex = true;
-        vertex_offset = acc;
-        break;
-      }
-      if (v + 1 < v1) acc += euclid(m.shape_x[v], m.shape_y[v], m.shape_x[v + 1], m.shape_y[v + 1]);
-    }
-    if (on_vertex) {
-      offset = vertex_offset;
-    } else {
-      double seen = 0.0, min_dist = SMX_INF, min_offset = -1.0;
-      for (int v = v0; v + 1 < v1; ++v) {
-        double x1 = m.shape_x[v], y1 = m.shape_y[v], x2 = m.shape_x[v + 1], y2 = m.shape_y[v + 1];
-        double d = euclid(x1, y1, x2, y2);
-        {
-          // a segment whose bounding box is farther than the best distance so far cannot lower
-          // the minimum (the first minimum wins, so ties need no visit either); `seen` still
-          // advances
-          const double gx = fmax(fmax(fmin(x1, x2) - px, px - fmax(x1, x2)), 0.0);
-          const double gy = fmax(fmax(fmin(y1, y2) - py, py - fmax(y1, y2)), 0.0);
-          const double keep = min_dist + 1e-6;
-          if (gx * gx + gy * gy > keep * keep) {
-            seen += d;
-            continue;
-          }
-        }
-        double u = ((px - x1) * (x2 - x1)) + ((py - y1) * (y2 - y1));
-        double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
-        double fx, fy;
-        position_at_offset(x1, y1, x2, y2, poff, fx, fy);
-        double dist = euclid(px, py, fx, fy);
-        if (dist < min_dist) {
-          min_dist = dist;
-          min_offset = poff + seen;
-        }
-        seen += d;
-      }
-      offset = min_offset;
-    }
-  }
-  // vector_at_offset
-  const double L = m.lane_length[lane];
-  double s_off, e_off;
-  if (offset >= L) {
-    s_off = L - 1.0;
-    e_off = L;
-  } else {
-    s_off = offset;
-    e_off = offset + 1.0;
-  }
-  s_off = fmax(s_off, 0.0);
-  double p1x, p1y, p2x, p2y;
-  position_at_shape_offset(m, v0, v1, s_off, p1x, p1y);
-  position_at_shape_offset(m, v0, v1, e_off, p2x, p2y);
-  double ang = vec_to_radians(p2x - p1x, p2y - p1y);
-  double half = ang * 0.5;
-  double qz = sin(half), qw = cos(half);
-  return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
-}
-
-
 // =================================================================================
 // k_control: controllers (a1-a3) + vehicle dynamics (a4-a6), SMX_WP_LANES lanes per vehicle.
 // The controller's waypoint query (lane_following_controller.py:96-98) is the long part: the team
@@ -468,11 +352,17 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
     RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), 4, cx, cy);
+    // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
+    // nearest lane closest to the vehicle; junction lanes are exempt (:548-551)
+    double lane_heading = 0.0;
+    const bool want_heading = h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
+    if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
     if (rank == 0) {
       fi[(size_t)SMX_FI_LANE * total + gid] = h.lane;
       fi[(size_t)SMX_FI_FLAGS * total + gid] =
           (h.on_road ? SMX_FACT_ON_ROAD : 0) | ((h.corner_mask & 15) << SMX_FACT_CORNER_SHIFT);
       a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid] = h.dist;
+      a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid] = lane_heading;
     }
   }
   // ---- path seeds
@@ -1019,7 +909,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
         is_off_route = false;
         is_wrong_way = false;
         if (!m.lane_in_junction[nl] && !(a.debug_skip & 64)) {
-          double target = lane_heading_at_point(m, nl, px, py);
+          const double target = a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid];  // k_scan
           is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
         }
       }
@@ -1477,6 +1367,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   ADD(lane_shape_off, nl + 1, int32_t);
   ADD(shape_x, nv, double);
   ADD(shape_y, nv, double);
+  ADD(shape_rec, nv, smx_shape_rec);
   ADD(lane_out_off, nl + 1, int32_t);
   ADD(lane_out_idx, t->lane_out_off[nl], int32_t);
   ADD(road_lane_off, nr + 1, int32_t);
@@ -1510,6 +1401,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   PTR(lane_shape_off, int32_t);
   PTR(shape_x, double);
   PTR(shape_y, double);
+  PTR(shape_rec, smx_shape_rec);
   PTR(lane_out_off, int32_t);
   PTR(lane_out_idx, int32_t);
   PTR(road_lane_off, int32_t);

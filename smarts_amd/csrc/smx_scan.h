@@ -318,3 +318,124 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
   }
   return s;
 }
+
+
+// ---------------------------------------------------------------------------------
+// lane heading at the centre-line point closest to (px, py):
+//   Lane.center_pose_at_point(point).heading  (road_map.py:390-396)
+//   = offset_along_lane (sumo_road_network.py:476-491, utils/math.py:370-390)
+//   + vector_at_offset (road_map.py:377-388) over from_lane_coord (utils/math.py:319-345)
+//   + Pose(fast_quaternion_from_angle(vec_to_radians(v))).heading (coordinates.py:394-403)
+// Team form of lane_heading_at_point (smx_kernels.hip): the lane's segments are strided over the
+// team; the running arclength of the reference's loops comes from smx_shape_rec.cum (summed on the
+// host vertex by vertex, the same additions), so every lane can evaluate its segments on its own.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_close_ref(double a, double b) {
+  return fabs(a - b) <= fmax(1e-09 * fmax(fabs(a), fabs(b)), 0.0);
+}
+
+__device__ __forceinline__ void position_at_offset(double x1, double y1, double x2, double y2, double dist,
+                                                   double offset, double& ox, double& oy) {
+  // utils/math.py:300-316; `dist` is the segment length
+  if (is_close_ref(offset, 0.0)) {
+    ox = x1;
+    oy = y1;
+    return;
+  }
+  if (is_close_ref(dist, offset)) {
+    ox = x2;
+    oy = y2;
+    return;
+  }
+  ox = x1 + (x2 - x1) * (offset / dist);
+  oy = y1 + (y2 - y1) * (offset / dist);
+}
+
+// position_at_shape_offset (utils/math.py:319-331): the first segment v with cum[v] + len[v] > offset
+__device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, int v1, double offset, double& ox,
+                                                     double& oy) {
+  const int r = team_rank();
+  int hit = 0x7fffffff;
+  for (int v = v0 + r; v + 1 < v1; v += SMX_TEAM) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.cum + a.len > offset) {
+      hit = v;
+      break;  // cum is non-decreasing along the lane
+    }
+  }
+#pragma unroll
+  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) hit = min(hit, __shfl_xor(hit, msk, SMX_TEAM));
+  if (hit == 0x7fffffff) {
+    const smx_shape_rec z = m.shape_rec[v1 - 1];
+    ox = z.x;
+    oy = z.y;
+    return;
+  }
+  const smx_shape_rec a = m.shape_rec[hit], b = m.shape_rec[hit + 1];
+  position_at_offset(a.x, a.y, b.x, b.y, a.len, offset - a.cum, ox, oy);
+}
+
+__device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  const int r = team_rank();
+  // ---- offset_along_lane: a vertex that equals the point wins (first such vertex) ...
+  int vertex_hit = 0x7fffffff;
+  // ... else the first segment at minimum distance
+  double min_dist = SMX_INF, min_offset = -1.0;
+  int min_v = 0x7fffffff;
+  for (int v = v0 + r; v < v1; v += SMX_TEAM) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.x == px && a.y == py) vertex_hit = min(vertex_hit, v);
+    if (v + 1 >= v1) continue;
+    const smx_shape_rec b = m.shape_rec[v + 1];
+    {
+      // a segment whose bounding box is farther than this lane's best so far can neither be the
+      // team's minimum nor tie it
+      const double gx = fmax(fmax(fmin(a.x, b.x) - px, px - fmax(a.x, b.x)), 0.0);
+      const double gy = fmax(fmax(fmin(a.y, b.y) - py, py - fmax(a.y, b.y)), 0.0);
+      const double keep = min_dist + 1e-6;
+      if (gx * gx + gy * gy > keep * keep) continue;
+    }
+    const double d = a.len;
+    const double u = ((px - a.x) * (b.x - a.x)) + ((py - a.y) * (b.y - a.y));
+    const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+    double fx, fy;
+    position_at_offset(a.x, a.y, b.x, b.y, d, poff, fx, fy);
+    const double dist = euclid(px, py, fx, fy);
+    if (dist < min_dist) {
+      min_dist = dist;
+      min_offset = poff + a.cum;
+      min_v = v;
+    }
+  }
+#pragma unroll
+  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) vertex_hit = min(vertex_hit, __shfl_xor(vertex_hit, msk, SMX_TEAM));
+  double offset;
+  if (vertex_hit != 0x7fffffff) {
+    offset = m.shape_rec[vertex_hit].cum;
+  } else {
+    double bd = min_dist;
+    int bv = min_v;
+    team_min_pair(bd, bv);  // smallest distance, then the earliest segment
+    const int owner = (bv == 0x7fffffff) ? 0 : ((bv - v0) & (SMX_TEAM - 1));
+    offset = __shfl(min_offset, owner, SMX_TEAM);
+  }
+  // ---- vector_at_offset
+  const double L = m.lane_length[lane];
+  double s_off, e_off;
+  if (offset >= L) {
+    s_off = L - 1.0;
+    e_off = L;
+  } else {
+    s_off = offset;
+    e_off = offset + 1.0;
+  }
+  s_off = fmax(s_off, 0.0);
+  double p1x, p1y, p2x, p2y;
+  team_position_at_shape_offset(m, v0, v1, s_off, p1x, p1y);
+  team_position_at_shape_offset(m, v0, v1, e_off, p2x, p2y);
+  const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
+  const double half = ang * 0.5;
+  const double qz = sin(half), qw = cos(half);
+  return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
+}

@@ -153,7 +153,7 @@ def map_tables_struct(cm: CompiledMap):
             arr = np.zeros(1, dtype=dt)
         keep.append(arr)
         setattr(t, name, arr.ctypes.data)
-    for name in ("lp_rec", "succ_rec", "lpg_pts", "sg_rec"):
+    for name in ("lp_rec", "succ_rec", "lpg_pts", "sg_rec", "shape_rec"):
         arr = np.ascontiguousarray(packed[name])
         if arr.size == 0:
             arr = np.zeros(1, dtype=arr.dtype)

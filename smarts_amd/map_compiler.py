@@ -397,6 +397,7 @@ LP_REC = np.dtype(
     [("x", "<f8"), ("y", "<f8"), ("heading", "<f8"), ("dirx", "<f8"), ("diry", "<f8"), ("lane", "<i4"),
      ("next_off", "<i4"), ("next0", "<i4"), ("n_next", "<u2"), ("inferred", "u1"), ("flags", "u1"),
      ("knot_next", "<i4"), ("knot_hops", "<i4")], align=False)
+SHAPE_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("cum", "<f8"), ("len", "<f8")], align=False)
 SUCC_REC = np.dtype([("idx", "<i4"), ("lane", "<i4"), ("knot", "<i4"), ("hops", "<i4")], align=False)
 PT_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("idx", "<i4"), ("lane", "<i4")], align=False)
 SEG_REC = np.dtype([("x1", "<f8"), ("y1", "<f8"), ("x2", "<f8"), ("y2", "<f8"), ("thr", "<f8"), ("lane", "<i4"),
@@ -468,4 +469,18 @@ def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
     # road_with_point threshold, the reference's expression (sumo_road_network.py:707)
     seg["thr"] = np.array([0.5 * float(w) + 1e-1 for w in cm.lane_width[lane]])
     seg["lane"] = lane
-    return dict(lp_rec=rec, succ_rec=succ, lpg_pts=pts, sg_rec=seg)
+    # centre-line vertices with their running arclength: the sums follow the reference's loops
+    # (utils/math.py:319-331, 370-390: `seen += length` vertex by vertex), so offsets compare equal
+    shp = np.zeros(len(cm.shape_x), dtype=SHAPE_REC)
+    shp["x"], shp["y"] = cm.shape_x, cm.shape_y
+    for lane in range(cm.n_lanes):
+        a, b = int(cm.lane_shape_off[lane]), int(cm.lane_shape_off[lane + 1])
+        acc = 0.0
+        for v in range(a, b):
+            shp["cum"][v] = acc
+            if v + 1 < b:
+                ex, ey = float(cm.shape_x[v] - cm.shape_x[v + 1]), float(cm.shape_y[v] - cm.shape_y[v + 1])
+                d = math.sqrt(ex * ex + ey * ey)
+                shp["len"][v] = d
+                acc = acc + d
+    return dict(lp_rec=rec, succ_rec=succ, lpg_pts=pts, sg_rec=seg, shape_rec=shp)
