@@ -218,49 +218,71 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     path.n = 0;
 #pragma unroll
     for (int k = 0; k < SMX_CTRL_WPS; ++k) path.x[k] = path.y[k] = path.h[k] = 0.0;
+    // Paths are numbered in the reference's order: seed lanes by index, branches depth-first.
+    // Team lane p walks seed lanes p, p + 4, ... on its own (no lane re-walks another lane's
+    // paths); counts are exchanged by shuffles to turn (lane, branch) into the global number.
+    // The first branch of the lane's first seed lane is synthesised in full while it is walked.
     int n_paths = 0;
     double my_d = SMX_INF;
     int my_idx = 0x7fffffff;
+    int goff0 = 0, cnt0 = 0;
     if (seed.road >= 0) {
-      // paths are numbered in the reference's order: lanes by index, branches depth-first.  Every
-      // lane walks every path (the walk discovers the branchings); lane (idx % 4) owns path idx.
-      for (int li = 0; li < seed.n_lanes; ++li) {
-        const int start = seed_start(m, seed, li, px, py);
-        if (start < 0) continue;
-        BranchState bs;
-        bs.reset();
-        do {
-          const bool mine = (n_paths % SMX_WP_LANES) == p0;
-          if (mine) {
-            double fx = 0.0, fy = 0.0;
-            if (n_paths < SMX_WP_LANES) {
-              path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
-                                           SMX_CTRL_WPS, [&](int i, const WaypointOut& w) {
-                                             ctrl_path_put(path, i, w.x, w.y, w.heading);
-                                             if (i == 0) {
-                                               fx = w.x;
-                                               fy = w.y;
-                                             }
-                                           });
-            } else {
-              equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 1,
-                                  [&](int, const WaypointOut& w) {
-                                    fx = w.x;
-                                    fy = w.y;
-                                  });
-            }
-            const double ex = fx - px, ey = fy - py;
-            const double d = sqrt(ex * ex + ey * ey);
-            if (d < my_d) {  // strict: the lowest-numbered path wins ties (np.argmin)
-              my_d = d;
-              my_idx = n_paths;
-            }
-          } else {
-            equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0,
-                                [&](int, const WaypointOut&) {});
+      for (int r4 = 0; r4 < seed.n_lanes; r4 += SMX_WP_LANES) {  // uniform within a team
+        const int li = r4 + p0;
+        int cnt = 0, bj = 0x7fffffff;
+        double bd = SMX_INF;
+        if (li < seed.n_lanes) {
+          const int start = seed_start(m, seed, li, px, py);
+          if (start >= 0) {
+            BranchState bs;
+            bs.reset();
+            do {
+              double fx = 0.0, fy = 0.0;
+              if (r4 == 0 && cnt == 0) {
+                path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
+                                             SMX_CTRL_WPS, [&](int i, const WaypointOut& w) {
+                                               ctrl_path_put(path, i, w.x, w.y, w.heading);
+                                               if (i == 0) {
+                                                 fx = w.x;
+                                                 fy = w.y;
+                                               }
+                                             });
+              } else {
+                equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 1,
+                                    [&](int, const WaypointOut& w) {
+                                      fx = w.x;
+                                      fy = w.y;
+                                    });
+              }
+              const double ex = fx - px, ey = fy - py;
+              const double d = sqrt(ex * ex + ey * ey);
+              if (d < bd) {  // strict: the lowest-numbered path wins ties (np.argmin)
+                bd = d;
+                bj = cnt;
+              }
+              ++cnt;
+            } while (bs.advance());
           }
-          ++n_paths;
-        } while (bs.advance());
+        }
+        // exclusive prefix of the counts over the team
+        int incl = cnt;
+        {
+          int t = __shfl_up(incl, 1, SMX_WP_LANES);
+          if (p0 >= 1) incl += t;
+          t = __shfl_up(incl, 2, SMX_WP_LANES);
+          if (p0 >= 2) incl += t;
+        }
+        const int round_total = __shfl(incl, SMX_WP_LANES - 1, SMX_WP_LANES);
+        const int g = n_paths + incl - cnt;
+        if (r4 == 0) {
+          goff0 = g;
+          cnt0 = cnt;
+        }
+        if (bj != 0x7fffffff && (bd < my_d || (bd == my_d && g + bj < my_idx))) {
+          my_d = bd;
+          my_idx = g + bj;
+        }
+        n_paths += round_total;
       }
     }
     // nearest path over the team: smallest distance, then smallest number
@@ -276,7 +298,30 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     if (n_paths > 0) {  // uniform within a team
       int want = my_idx + lane_change;
       want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
-      const int src = want < SMX_WP_LANES ? want : 0;
+      // the lane whose first seed lane holds path `want`
+      const bool own = cnt0 > 0 && want >= goff0 && want < goff0 + cnt0;
+      if (own && want > goff0) {
+        // a later branch of this lane's seed lane: walk to it again (rare: branching inside 16 hops)
+        const int start = seed_start(m, seed, p0, px, py);
+        BranchState bs;
+        bs.reset();
+        int j = 0;
+        do {
+          if (j == want - goff0) {
+            path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
+                                         SMX_CTRL_WPS,
+                                         [&](int i, const WaypointOut& w) { ctrl_path_put(path, i, w.x, w.y, w.heading); });
+            break;
+          }
+          equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0,
+                              [&](int, const WaypointOut&) {});
+          ++j;
+        } while (bs.advance());
+      }
+      int owners = own ? (1 << p0) : 0;
+#pragma unroll
+      for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) owners |= __shfl_xor(owners, msk, SMX_WP_LANES);
+      const int src = owners ? (__ffs(owners) - 1) : 0;
       CtrlPath chosen;
       chosen.n = __shfl(path.n, src, SMX_WP_LANES);
 #pragma unroll
@@ -286,7 +331,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
         chosen.h[k] = team4_get(path.h[k], src);
       }
       if (p0 == 0) {
-        if (want >= SMX_WP_LANES) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, chosen);
+        // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
+        if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, chosen);
         co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, chosen);
       }
     } else {
@@ -389,237 +435,234 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
 
 // =================================================================================
 // k_waypoints: waypoint paths (sensors.py:268-275, 972-985) + trip meter (sensors.py:880-947).
-// SMX_WP_LANES lanes per vehicle: lane p synthesises kept path p (p + 4, ...); results are staged
-// in LDS in the exact byte layout of the dense outputs and leave as whole 16-byte pieces.
+// SMX_WP_LANES lanes per vehicle.  Team lane p takes seed lane p and writes its first path straight
+// into the dense rows at the slot it would have if no lower seed lane branches (its provisional
+// number); the team then exchanges the real counts.  Almost always that guess was right and every
+// lane has walked exactly one path.  Otherwise (a branching inside the lookahead, or a road with
+// more than four lanes) the team numbers the paths the long way and rewrites the rows.
+// Rows are written whole every tick (unused waypoints and paths as zeros, format_obs.py:589-596),
+// each lane streaming its own row in order, so L2 assembles full lines before they leave.
 // =================================================================================
-struct WpStageLayout {
-  int per_vehicle;  // bytes of staged waypoint data per vehicle
-  int off_pos, off_heading, off_width, off_speed, off_lidx, off_lid;
+struct WpRows {
+  double* pos;
+  float *heading, *width, *speed;
+  int16_t* lid;
+  int8_t* lidx;
 };
 
-__device__ __forceinline__ WpStageLayout wp_layout(int P, int W) {
-  WpStageLayout L;
-  const int n = P * W;
-  L.off_pos = 0;
-  L.off_heading = n * 24;
-  L.off_width = L.off_heading + n * 4;
-  L.off_speed = L.off_width + n * 4;
-  L.off_lid = L.off_speed + n * 4;
-  L.off_lidx = L.off_lid + n * 2;
-  L.per_vehicle = (L.off_lidx + n + 15) & ~15;
-  return L;
+__device__ __forceinline__ WpRows wp_rows(const smx_outputs& o, size_t gid, int P, int W, int slot) {
+  const size_t q = (gid * P + slot) * (size_t)W;
+  WpRows r;
+  r.pos = o.wp_pos + q * 3;
+  r.heading = o.wp_heading + q;
+  r.width = o.wp_lane_width + q;
+  r.speed = o.wp_speed_limit + q;
+  r.lid = o.wp_lane_id + q;
+  r.lidx = o.wp_lane_index + q;
+  return r;
+}
+
+__device__ __forceinline__ void wp_put(const MapDev& m, const WpRows& r, int i, const WaypointOut& w) {
+  r.pos[i * 3 + 0] = w.x;
+  r.pos[i * 3 + 1] = w.y;
+  r.pos[i * 3 + 2] = 0.0;
+  r.heading[i] = (float)w.heading;
+  r.width[i] = (float)w.width;
+  r.speed[i] = (float)w.speed;
+  r.lid[i] = (int16_t)w.lane;
+  r.lidx[i] = (int8_t)m.lane_index[w.lane];
+}
+
+__device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
+  for (int i = from; i < W; ++i) {
+    r.pos[i * 3 + 0] = 0.0;
+    r.pos[i * 3 + 1] = 0.0;
+    r.pos[i * 3 + 2] = 0.0;
+    r.heading[i] = 0.0f;
+    r.width[i] = 0.0f;
+    r.speed[i] = 0.0f;
+    r.lid[i] = -1;
+    r.lidx[i] = 0;
+  }
 }
 
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
-  extern __shared__ __align__(16) unsigned char stage[];
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
-  __shared__ int veh_live[SMX_BLOCK / SMX_WP_LANES];
   int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const int VPB = SMX_BLOCK / SMX_WP_LANES;  // vehicles per block
-  const int vloc = threadIdx.x / SMX_WP_LANES;
   const int p0 = threadIdx.x % SMX_WP_LANES;
-  const size_t gid = (size_t)blockIdx.x * VPB + vloc;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
+  if (gid >= total) return;  // whole teams leave together
+  int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE) || (a.first_only && !(flags & SMX_F_FIRST))) return;
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   const int P = c.wp_paths, W = c.wp_len;
-  const WpStageLayout L = wp_layout(P, W);
-  unsigned char* mine = stage + (size_t)vloc * L.per_vehicle;
+  const VehState s = load_vehicle(a, gid, total);
+  const double px = s.x, py = s.y;
 
-  int flags = 0;
-  bool live = false;
-  if (gid < total) {
-    flags = a.st.flags[gid];
-    live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
-  }
-  if (p0 == 0) veh_live[vloc] = live ? 1 : 0;
-  // zero the staging area (padding rows / unused paths are zeros, format_obs.py:589-596)
-  if (wp_on) {
-    const int words = (VPB * L.per_vehicle) / 4;
-    for (int k = threadIdx.x; k < words; k += SMX_BLOCK) reinterpret_cast<int*>(stage)[k] = 0;
-  }
-  __syncthreads();
-
-  bool have_first_wp = false;
+  bool have_first_wp = false;  // first waypoint of path 0 (trip meter), valid on team lane 0
   double fwx = 0, fwy = 0, fwh = 0;
-  int n_paths_total = 0;
-  if (live) {
-    const VehState s = load_vehicle(a, gid, total);
-    const double px = s.x, py = s.y;
-    const PathSeeds seed = load_seeds(a, gid, total);
-    const int lookahead = wp_on ? c.wp_lookahead : 1;
-    if (wp_on) {
-      // -1 lane ids for the rows that stay empty
-      short* lid = reinterpret_cast<short*>(mine + L.off_lid);
-      for (int k = p0; k < P * W; k += SMX_WP_LANES) lid[k] = -1;
+  if (!wp_on) {
+    // only the first waypoint of the first path is needed (trip meter)
+    const int os = a.st.facts_i32[(size_t)SMX_FI_OBS_START * total + gid];
+    if (p0 == 0 && os >= 0) {
+      BranchState bs;
+      bs.reset();
+      RouteFilter nof;
+      nof.n = 0;
+      equally_spaced_path(m, nof, bs, os, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+        have_first_wp = true;
+        fwx = w.x;
+        fwy = w.y;
+        fwh = w.heading;
+      });
     }
-    if (!wp_on) {
-      // only the first waypoint of the first path is needed (trip meter)
-      const int os = a.st.facts_i32[(size_t)SMX_FI_OBS_START * total + gid];
-      if (p0 == 0 && os >= 0) {
-        BranchState bs;
-        bs.reset();
-        RouteFilter nof;
-        nof.n = 0;
-        equally_spaced_path(m, nof, bs, os, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
-          have_first_wp = true;
-          fwx = w.x;
-          fwy = w.y;
-          fwh = w.heading;
-        });
-      }
-    } else if (seed.road >= 0 && !(a.debug_skip & 16)) {
-      // enumerate the paths in the reference's order (lanes by index, branches depth-first); lane p0
-      // synthesises paths p0, p0 + 4, ...; lane 0 also counts them all
-      int idx = 0;
-      for (int li = 0; li < seed.n_lanes; ++li) {
-        int start = seed_start(m, seed, li, px, py);
-        if (start < 0) continue;
+  } else {
+    const PathSeeds seed = load_seeds(a, gid, total);
+    const int lookahead = c.wp_lookahead;
+    int n_paths_total = 0;
+    if (seed.road >= 0 && !(a.debug_skip & 16)) {
+      // ---- the guess: seed lane p holds exactly one path
+      const int start = (p0 < seed.n_lanes) ? seed_start(m, seed, p0, px, py) : -1;
+      int started = start >= 0 ? (1 << p0) : 0;
+#pragma unroll
+      for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) started |= __shfl_xor(started, msk, SMX_WP_LANES);
+      const int prov = __popc(started & ((1 << p0) - 1));
+      int cnt = 0;
+      double gx = 0, gy = 0, gh = 0;  // first waypoint of this lane's first path
+      if (start >= 0) {
         BranchState bs;
         bs.reset();
         do {
-          const bool kept = wp_on && idx < P && (idx % SMX_WP_LANES) == p0;
-          const bool first_path = (idx == 0 && p0 == 0);
-          if (kept || first_path) {
-            const int base = idx * W;
-            const int max_emit = kept ? W : 1;
-            int n = equally_spaced_path(
-                m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, max_emit, [&](int i, const WaypointOut& w) {
-                  if (first_path && i == 0) {
-                    have_first_wp = true;
-                    fwx = w.x;
-                    fwy = w.y;
-                    fwh = w.heading;
-                  }
-                  if (kept) {
-                    const int q = base + i;
-                    double* pos = reinterpret_cast<double*>(mine + L.off_pos) + (size_t)q * 3;
-                    pos[0] = w.x;
-                    pos[1] = w.y;
-                    pos[2] = 0.0;
-                    reinterpret_cast<float*>(mine + L.off_heading)[q] = (float)w.heading;
-                    reinterpret_cast<float*>(mine + L.off_width)[q] = (float)w.width;
-                    reinterpret_cast<float*>(mine + L.off_speed)[q] = (float)w.speed;
-                    reinterpret_cast<short*>(mine + L.off_lid)[q] = (short)w.lane;
-                    reinterpret_cast<signed char*>(mine + L.off_lidx)[q] = (signed char)m.lane_index[w.lane];
-                  }
-                });
-            if (kept) o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
-          } else if (p0 == 0 || idx < P) {
-            // walk only: discovers the branchings (and, on lane 0, counts the path)
+          if (cnt == 0 && prov < P) {
+            const WpRows rows = wp_rows(o, gid, P, W, prov);
+            const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, W,
+                                              [&](int i, const WaypointOut& w) {
+                                                if (i == 0) {
+                                                  gx = w.x;
+                                                  gy = w.y;
+                                                  gh = w.heading;
+                                                }
+                                                wp_put(m, rows, i, w);
+                                              });
+            wp_zero(rows, n < W ? n : W, W);
+            o.wp_count[gid * (P + 1) + 1 + prov] = (uint8_t)(n < W ? n : W);
+          } else {
             equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, 0,
                                 [&](int, const WaypointOut&) {});
           }
-          ++idx;
-        } while (bs.advance() && (p0 == 0 || idx < P));
+          ++cnt;
+        } while (bs.advance());
       }
-      n_paths_total = idx;
-    }
-    if (p0 == 0) {
-      if (wp_on) {
-        o.wp_count[gid * (P + 1)] = (uint8_t)(n_paths_total > 255 ? 255 : n_paths_total);
-        for (int p = n_paths_total; p < P; ++p) o.wp_count[gid * (P + 1) + 1 + p] = 0;
-      }
-      // ---- trip meter (sensors.py:880-947); reward = increment (agent_manager.py:233-234)
-      double dist = SF(SMX_S_DIST);
-      if (flags & SMX_F_FIRST) {
-        // TripMeterSensor.__init__: first waypoint of the lowest lane, lookahead-1 path, no route
-        flags &= ~SMX_F_TRIP_HAS_WP;
-        const int ts = a.st.facts_i32[(size_t)SMX_FI_TRIP_START * total + gid];
-        if (ts >= 0) {
+      int branching = (cnt > 1) ? 1 : 0;
+#pragma unroll
+      for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) branching |= __shfl_xor(branching, msk, SMX_WP_LANES);
+      if (!branching && seed.n_lanes <= SMX_WP_LANES) {
+        // ---- the guess held: path numbers are the provisional ones
+        n_paths_total = __popc(started);
+        const int src = started ? (__ffs(started) - 1) : 0;
+        fwx = __shfl(gx, src, SMX_WP_LANES);
+        fwy = __shfl(gy, src, SMX_WP_LANES);
+        fwh = __shfl(gh, src, SMX_WP_LANES);
+        have_first_wp = n_paths_total > 0;
+      } else {
+        // ---- number the paths the long way (lanes by index, branches depth-first): every lane
+        // walks every path to discover the branchings, lane (idx % 4) writes kept path idx
+        int idx = 0;
+        for (int li = 0; li < seed.n_lanes; ++li) {
+          const int st = seed_start(m, seed, li, px, py);
+          if (st < 0) continue;
           BranchState bs;
           bs.reset();
-          RouteFilter nof;
-          nof.n = 0;
-          equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
-            SF(SMX_S_TRIP_X) = w.x;
-            SF(SMX_S_TRIP_Y) = w.y;
-            SF(SMX_S_TRIP_H) = w.heading;
-            flags |= SMX_F_TRIP_HAS_WP;
-          });
+          do {
+            const bool kept = idx < P && (idx % SMX_WP_LANES) == p0;
+            const bool first_path = (idx == 0 && p0 == 0);
+            if (kept || first_path) {
+              const WpRows rows = wp_rows(o, gid, P, W, kept ? idx : 0);
+              const int n = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, SMX_BLOCK, kept ? W : 1,
+                                                [&](int i, const WaypointOut& w) {
+                                                  if (first_path && i == 0) {
+                                                    have_first_wp = true;
+                                                    fwx = w.x;
+                                                    fwy = w.y;
+                                                    fwh = w.heading;
+                                                  }
+                                                  if (kept) wp_put(m, rows, i, w);
+                                                });
+              if (kept) {
+                wp_zero(rows, n < W ? n : W, W);
+                o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+              }
+            } else if (p0 == 0 || idx < P) {
+              equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, SMX_BLOCK, 0,
+                                  [&](int, const WaypointOut&) {});
+            }
+            ++idx;
+          } while (bs.advance() && (p0 == 0 || idx < P));
         }
-        dist = 0.0;
+        n_paths_total = __shfl(idx, 0, SMX_WP_LANES);  // lane 0 counts them all
       }
-      const double last_dist = dist;
-      if (have_first_wp) {
-        if (!(flags & SMX_F_TRIP_HAS_WP)) {
-          SF(SMX_S_TRIP_X) = fwx;
-          SF(SMX_S_TRIP_Y) = fwy;
-          SF(SMX_S_TRIP_H) = fwh;
-          flags |= SMX_F_TRIP_HAS_WP;
-        } else {
-          double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
-          double dx = fwx - tx, dy = fwy - ty;
-          double nrm = sqrt(dx * dx + dy * dy);
-          if (nrm > 0.5) {
-            double hvx, hvy;
-            radians_to_vec(th, hvx, hvy);
-            double dot = hvx * dx + hvy * dy;
-            double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
-            dist += sgn * nrm;
-            SF(SMX_S_TRIP_X) = fwx;
-            SF(SMX_S_TRIP_Y) = fwy;
-            SF(SMX_S_TRIP_H) = fwh;
-          }
-        }
-      }
-      SF(SMX_S_DIST) = dist;
-      o.dist[gid] = dist;
-      if (!a.keep_reward_done) o.reward[gid] = dist - last_dist;
-      // only the trip-meter bit may change here; k_observe owns the other flag bits
-      a.st.flags[gid] = (a.st.flags[gid] & ~SMX_F_TRIP_HAS_WP) | (flags & SMX_F_TRIP_HAS_WP);
     }
+    // rows of the paths that do not exist
+    for (int slot = n_paths_total + ((p0 - n_paths_total) & (SMX_WP_LANES - 1)); slot < P; slot += SMX_WP_LANES) {
+      wp_zero(wp_rows(o, gid, P, W, slot), 0, W);
+      o.wp_count[gid * (P + 1) + 1 + slot] = 0;
+    }
+    if (p0 == 0) o.wp_count[gid * (P + 1)] = (uint8_t)(n_paths_total > 255 ? 255 : n_paths_total);
   }
-  __syncthreads();
-  // ---- copy-out: each array's slice of a vehicle is contiguous in global memory, and so are
-  // consecutive vehicles, so the block's staged bytes leave as runs of 16-byte pieces
-  if (wp_on) {
-    const size_t v0 = (size_t)blockIdx.x * VPB;
-    const int n = P * W;
-    struct Seg {
-      unsigned char* dst;
-      int off, bytes;
-    };
-    const Seg segs[6] = {
-        {reinterpret_cast<unsigned char*>(o.wp_pos), L.off_pos, n * 24},
-        {reinterpret_cast<unsigned char*>(o.wp_heading), L.off_heading, n * 4},
-        {reinterpret_cast<unsigned char*>(o.wp_lane_width), L.off_width, n * 4},
-        {reinterpret_cast<unsigned char*>(o.wp_speed_limit), L.off_speed, n * 4},
-        {reinterpret_cast<unsigned char*>(o.wp_lane_id), L.off_lid, n * 2},
-        {reinterpret_cast<unsigned char*>(o.wp_lane_index), L.off_lidx, n},
-    };
-#pragma unroll
-    for (int sgi = 0; sgi < 6; ++sgi) {
-      const int bytes = segs[sgi].bytes;
-      if ((bytes & 15) == 0) {
-        const int pieces = bytes / 16;
-        for (int k = threadIdx.x; k < VPB * pieces; k += SMX_BLOCK) {
-          const int v = k / pieces, w = k - v * pieces;
-          if (v0 + v >= total || !veh_live[v]) continue;
-          const int4 val = *reinterpret_cast<const int4*>(stage + (size_t)v * L.per_vehicle + segs[sgi].off + w * 16);
-          *reinterpret_cast<int4*>(segs[sgi].dst + (v0 + v) * (size_t)bytes + (size_t)w * 16) = val;
-        }
-      } else {
-        const int pieces = bytes / 4;  // every slice is a multiple of 4 bytes for even P * W
-        const int tail = bytes & 3;
-        for (int k = threadIdx.x; k < VPB * pieces; k += SMX_BLOCK) {
-          const int v = k / pieces, w = k - v * pieces;
-          if (v0 + v >= total || !veh_live[v]) continue;
-          const int val = *reinterpret_cast<const int*>(stage + (size_t)v * L.per_vehicle + segs[sgi].off + w * 4);
-          *reinterpret_cast<int*>(segs[sgi].dst + (v0 + v) * (size_t)bytes + (size_t)w * 4) = val;
-        }
-        if (tail) {
-          for (int k = threadIdx.x; k < VPB * tail; k += SMX_BLOCK) {
-            const int v = k / tail, w = pieces * 4 + (k - v * tail);
-            if (v0 + v >= total || !veh_live[v]) continue;
-            segs[sgi].dst[(v0 + v) * (size_t)bytes + w] = stage[(size_t)v * L.per_vehicle + segs[sgi].off + w];
-          }
-        }
+
+  if (p0 != 0) return;
+  // ---- trip meter (sensors.py:880-947); reward = increment (agent_manager.py:233-234)
+  double dist = SF(SMX_S_DIST);
+  if (flags & SMX_F_FIRST) {
+    // TripMeterSensor.__init__: first waypoint of the lowest lane, lookahead-1 path, no route
+    flags &= ~SMX_F_TRIP_HAS_WP;
+    const int ts = a.st.facts_i32[(size_t)SMX_FI_TRIP_START * total + gid];
+    if (ts >= 0) {
+      BranchState bs;
+      bs.reset();
+      RouteFilter nof;
+      nof.n = 0;
+      equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+        SF(SMX_S_TRIP_X) = w.x;
+        SF(SMX_S_TRIP_Y) = w.y;
+        SF(SMX_S_TRIP_H) = w.heading;
+        flags |= SMX_F_TRIP_HAS_WP;
+      });
+    }
+    dist = 0.0;
+  }
+  const double last_dist = dist;
+  if (have_first_wp) {
+    if (!(flags & SMX_F_TRIP_HAS_WP)) {
+      SF(SMX_S_TRIP_X) = fwx;
+      SF(SMX_S_TRIP_Y) = fwy;
+      SF(SMX_S_TRIP_H) = fwh;
+      flags |= SMX_F_TRIP_HAS_WP;
+    } else {
+      double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
+      double dx = fwx - tx, dy = fwy - ty;
+      double nrm = sqrt(dx * dx + dy * dy);
+      if (nrm > 0.5) {
+        double hvx, hvy;
+        radians_to_vec(th, hvx, hvy);
+        double dot = hvx * dx + hvy * dy;
+        double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
+        dist += sgn * nrm;
+        SF(SMX_S_TRIP_X) = fwx;
+        SF(SMX_S_TRIP_Y) = fwy;
+        SF(SMX_S_TRIP_H) = fwh;
       }
     }
   }
+  SF(SMX_S_DIST) = dist;
+  o.dist[gid] = dist;
+  if (!a.keep_reward_done) o.reward[gid] = dist - last_dist;
+  // only the trip-meter bit may change here; k_observe owns the other flag bits
+  a.st.flags[gid] = (a.st.flags[gid] & ~SMX_F_TRIP_HAS_WP) | (flags & SMX_F_TRIP_HAS_WP);
 }
 
 // =================================================================================
@@ -1484,12 +1527,6 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
   const int epb = SMX_BLOCK / c.num_vehicles;
   const int obs_blocks = (c.num_envs + epb - 1) / epb;
   const int env_blocks = (c.num_envs + SMX_BLOCK - 1) / SMX_BLOCK;
-  size_t stage_bytes = 0;
-  if (c.sensors & SMX_SENSOR_WAYPOINTS) {
-    const size_t n = (size_t)c.wp_paths * c.wp_len;
-    const size_t per = ((n * 24 + n * 4 * 3 + n * 2 + n) + 15) & ~size_t(15);
-    stage_bytes = per * vpb;
-  }
   const bool timed = h->timing && is_step && h->ev_used < 65536;
   if (timed) {
     if (h->ev_pool.size() < 2 * (h->ev_used + 1)) {
@@ -1526,7 +1563,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     SMX_PHASE_END(SMX_PHASE_OGM);
     if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_LIDAR);
-    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, a);
+    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_WAYPOINTS);
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_OBSERVE);
@@ -1543,7 +1580,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     if (c.sensors & SMX_SENSOR_OGM)
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, r);
     if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, r);
-    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, r);
+    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, r);
     hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
