@@ -39,6 +39,17 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(suffix: str, defines) -> str:
+    """Developer variants (e.g. ``_prof`` with -DSMX_DEBUG_TIMING); selected with $SMX_LIBRARY."""
+    out = os.path.join(HERE, LIB_NAME.replace(".so", f"{suffix}.so"))
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", *FLAGS, *[f"-D{d}" for d in defines],
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
@@ -54,4 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--prof" in sys.argv:
+        print(build_variant("_prof", ["SMX_DEBUG_TIMING"]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
+  SMX_TSTAMP(tc0);
   VehState s = load_vehicle(a, gid, total);
   CtrlState cs;
   cs.lat_int = SF(SMX_S_LAT_INT);
@@ -226,6 +227,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     double my_d = SMX_INF;
     int my_idx = 0x7fffffff;
     int goff0 = 0, cnt0 = 0;
+    SMX_TSTAMP(tc1);
+    SMX_TACC(15, tc0, tc1);
     if (seed.road >= 0) {
       for (int r4 = 0; r4 < seed.n_lanes; r4 += SMX_WP_LANES) {  // uniform within a team
         const int li = r4 + p0;
@@ -285,6 +288,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
         n_paths += round_total;
       }
     }
+    SMX_TSTAMP(tc2);
+    SMX_TACC(16, tc1, tc2);
     // nearest path over the team: smallest distance, then smallest number
 #pragma unroll
     for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) {
@@ -330,11 +335,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
         chosen.y[k] = team4_get(path.y[k], src);
         chosen.h[k] = team4_get(path.h[k], src);
       }
+      SMX_TSTAMP(tc3);
+      SMX_TACC(17, tc2, tc3);
       if (p0 == 0) {
         // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
         if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, chosen);
         co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, chosen);
       }
+      SMX_TSTAMP(tc4);
+      SMX_TACC(18, tc3, tc4);
     } else {
       // reference asserts "no waypoints found"; keep the last command
       co.throttle = cs.throttle;
@@ -343,9 +352,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     }
   }
   if (p0 != 0) return;
+  SMX_TSTAMP(tc5);
   SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
   SF(SMX_S_PREV_Y) = s.y;
   vehicle_step(s, co, c.dt);
+  SMX_TSTAMP(tc6);
+  SMX_TACC(19, tc5, tc6);
   SF(SMX_S_X) = s.x;
   SF(SMX_S_Y) = s.y;
   SF(SMX_S_HEADING) = s.heading;
@@ -361,6 +373,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   SF(SMX_S_MCL_X) = cs.mcl_x;
   SF(SMX_S_MCL_Y) = cs.mcl_y;
   a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
+  SMX_TSTAMP(tc7);
+  SMX_TACC(20, tc0, tc7);
 }
 
 // =================================================================================
@@ -382,6 +396,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
+  SMX_TSTAMP(ts0);
   const VehState s = load_vehicle(a, gid, total);
   int32_t* fi = a.st.facts_i32;
   // ---- road facts
@@ -398,11 +413,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
     RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), 4, cx, cy);
+    SMX_TSTAMP(ts1);
+    SMX_TACC(10, ts0, ts1);
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
     // nearest lane closest to the vehicle; junction lanes are exempt (:548-551)
     double lane_heading = 0.0;
     const bool want_heading = h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
     if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
+    SMX_TSTAMP(ts2);
+    SMX_TACC(11, ts1, ts2);
     if (rank == 0) {
       fi[(size_t)SMX_FI_LANE * total + gid] = h.lane;
       fi[(size_t)SMX_FI_FLAGS * total + gid] =
@@ -412,8 +431,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
     }
   }
   // ---- path seeds
+  SMX_TSTAMP(ts3);
   Top10 t;
   team_nearest10(m, s.x, s.y, t);
+  SMX_TSTAMP(ts4);
+  SMX_TACC(12, ts3, ts4);
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   // what the controller (and the waypoints sensor) ask: paths at this pose with the agent's route
   const PathSeeds seed = team_compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true, t);
@@ -426,11 +448,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }
+  SMX_TSTAMP(ts5);
+  SMX_TACC(13, ts4, ts5);
   if (rank == 0) {
     store_seeds(a, gid, total, seed);
     fi[(size_t)SMX_FI_TRIP_START * total + gid] = (flags & SMX_F_FIRST) ? trip_start : -1;
     fi[(size_t)SMX_FI_OBS_START * total + gid] = obs_start;
   }
+  SMX_TSTAMP(ts6);
+  SMX_TACC(14, ts0, ts6);
 }
 
 // =================================================================================
@@ -669,6 +695,22 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
 // k_observe: the rest of Sensors.observe (sensors.py:238-396) and the events / done logic
 // (sensors.py:443-594), one thread per vehicle, whole envs per workgroup (env-mates' poses in LDS)
 // =================================================================================
+// A vehicle of a freshly reset env: state from the spawn table row of `episode`
+// (SMARTS.reset / TrapManager, smarts.py:365-460, trap_manager.py:212-230).
+__device__ __forceinline__ void respawn_vehicle(const KernelArgs& a, size_t gid, size_t total, int episode) {
+  const int row = a.sp.episodes > 0 ? (((episode % a.sp.episodes) + a.sp.episodes) % a.sp.episodes) : 0;
+  const double* sp = a.sp.pose + ((size_t)row * total + gid) * 4;
+  for (int f = 0; f < SMX_S_COUNT; ++f) SF(f) = 0.0;
+  SF(SMX_S_X) = sp[0];
+  SF(SMX_S_Y) = sp[1];
+  SF(SMX_S_HEADING) = wrap_heading(sp[2]);
+  SF(SMX_S_U) = sp[3];
+  SF(SMX_S_PREV_X) = sp[0];
+  SF(SMX_S_PREV_Y) = sp[1];
+  a.st.flags[gid] = SMX_F_ALIVE | SMX_F_FIRST;
+  a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
+}
+
 struct __align__(16) SharedPose {
   double x, y, heading, speed;
   double lane_dist;
@@ -994,6 +1036,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
     }
   }
   __syncthreads();
+  __shared__ int env_respawn[SMX_BLOCK];
+  if (slot == 0 && env_local < epb) env_respawn[env_local] = 0;
   if (valid && slot == 0) {
     if (!a.first_only) {
       int dcnt = a.st.env_done_count[env] + env_new_done[env_local];
@@ -1001,10 +1045,26 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
       a.st.env_ticks[env] = a.st.env_ticks[env] + 1;
       bool all_done = dcnt >= n_veh;  // hiway_env.py:258-261
       o.env_done[env] = all_done ? 1 : 0;
-      a.st.env_reset_pending[env] = (all_done && c.auto_reset) ? 1 : 0;
+      a.st.env_reset_pending[env] = 0;
+      env_respawn[env_local] = (all_done && c.auto_reset) ? 1 : 0;
     } else if (!a.keep_reward_done) {
       if (a.st.env_done_count[env] == 0 && pose[env_local * n_veh].alive) o.env_done[env] = 0;
     }
+  }
+  __syncthreads();
+  // ---- auto-reset (parallel_env.py:303-309): an env whose agents are all done starts its next
+  // episode here; the reset pass that follows this kernel builds the first observations
+  const bool respawn = valid && env_respawn[env_local] != 0;
+  int next_episode = 0;
+  if (respawn) {
+    next_episode = a.st.env_episode[env] + 1;
+    respawn_vehicle(a, gid, total, next_episode);
+  }
+  __syncthreads();  // every thread of the env has read env_episode
+  if (respawn && slot == 0) {
+    a.st.env_episode[env] = next_episode;
+    a.st.env_done_count[env] = 0;
+    a.st.env_ticks[env] = c.reset_elapsed_steps;
   }
 }
 
@@ -1205,18 +1265,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_reset(const KernelArgs a) {
   else
     sel = a.st.env_reset_pending[env] != 0;
   if (!sel) return;
-  const int episode = a.st.env_episode[env] + 1;  // every reset starts the next spawn row
-  const int row = a.sp.episodes > 0 ? (((episode % a.sp.episodes) + a.sp.episodes) % a.sp.episodes) : 0;
-  const double* sp = a.sp.pose + ((size_t)row * total + gid) * 4;
-  for (int f = 0; f < SMX_S_COUNT; ++f) SF(f) = 0.0;
-  SF(SMX_S_X) = sp[0];
-  SF(SMX_S_Y) = sp[1];
-  SF(SMX_S_HEADING) = wrap_heading(sp[2]);
-  SF(SMX_S_U) = sp[3];
-  SF(SMX_S_PREV_X) = sp[0];
-  SF(SMX_S_PREV_Y) = sp[1];
-  a.st.flags[gid] = SMX_F_ALIVE | SMX_F_FIRST;
-  a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
+  respawn_vehicle(a, gid, total, a.st.env_episode[env] + 1);  // every reset starts the next spawn row
   // per-env words are written by every thread of the env with the same values (no ordering needed
   // inside this kernel; the env's own threads never read them here)
   (void)slot;
@@ -1574,8 +1623,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
     r.keep_reward_done = is_step ? 1 : 0;
     r.reset_all = (!is_step && mask == nullptr) ? 1 : 0;
     r.env_mask = is_step ? nullptr : mask;
-    hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
-    hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    if (!is_step) {  // in a step, k_observe has already respawned the envs that ended
+      hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
+      hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    }
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
     if (c.sensors & SMX_SENSOR_OGM)
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, r);

@@ -17,7 +17,9 @@ torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 24)(); lib.smx_prof_read(b
 T = 50
 for _ in range(T): sim.step(acts)
 torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
-waves = (E * N + 63) // 64
-names = {0: 'total(step part)', 1: 'control', 2: 'dynamics', 3: 'pose scan+barrier', 4: 'collisions', 5: 'obs: ego/accel/neighbours', 6: 'obs: path seeds (NN)', 7: 'obs: trip init+waypoint paths', 8: 'obs: trip/driven/events', 9: 'observe total+store'}
-for k in range(10):
-    print(f'{names[k]:32s} {buf[k] / T / waves / 100.0:10.1f} us/wave (100 MHz clock)')
+names = {10: 'scan: road facts (8 lanes/veh)', 11: 'scan: lane heading', 12: 'scan: nearest10', 13: 'scan: path seeds', 14: 'scan: total',
+         15: 'control: loads', 16: 'control: path walk+synth', 17: 'control: reduce+shuffle', 18: 'control: law (lane 0)', 19: 'control: physics', 20: 'control: total (lane-0 waves)'}
+lanes = {10: 8, 11: 8, 12: 8, 13: 8, 14: 8, 15: 4, 16: 4, 17: 4, 18: 4, 19: 4, 20: 4}
+for k in sorted(names):
+    waves = (E * N * lanes[k] + 63) // 64
+    print(f'{names[k]:36s} {buf[k] / T / waves / 100.0:10.2f} us/wave (100 MHz clock)')
