@@ -390,7 +390,10 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
+  // the two halves of the scan are independent, so they run as different workgroups of one launch
+  // (even: road facts + lane heading, odd: lanepoint search + path seeds) and overlap in time
+  const int role = blockIdx.x & 1;
+  const size_t gid = ((size_t)(blockIdx.x >> 1) * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
   const int rank = team_rank();
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
@@ -399,8 +402,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   SMX_TSTAMP(ts0);
   const VehState s = load_vehicle(a, gid, total);
   int32_t* fi = a.st.facts_i32;
-  // ---- road facts
-  {
+  if (role == 0) {
+    // ---- road facts
     const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
     const double cys[4] = {0.5, 0.5, -0.5, -0.5};
     double cx[4], cy[4];
@@ -429,6 +432,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
       a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid] = h.dist;
       a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid] = lane_heading;
     }
+    return;
   }
   // ---- path seeds
   SMX_TSTAMP(ts3);
@@ -1570,7 +1574,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
   a.debug_skip = h->debug_skip;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
-  const int scan_blocks = (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
+  const int scan_blocks = 2 * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);  // two roles per vehicle group
   const int vpb = SMX_BLOCK / SMX_WP_LANES;
   const int wp_blocks = (int)((total + vpb - 1) / vpb);
   const int epb = SMX_BLOCK / c.num_vehicles;
