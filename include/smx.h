@@ -81,6 +81,19 @@ enum {
   SMX_SENSOR_LIDAR = 1 << 4
 };
 
+/* ActionSpaceType (controllers/__init__.py:42-57) values on this path.  Lane takes int8 codes
+ * (smx_step); the others take three floats per agent (smx_step_continuous):
+ *   CONTINUOUS                 throttle, brake, steering                  (:94-99)
+ *   ACTUATOR_DYNAMIC           throttle, brake, steering rate             (actuator_dynamic_controller.py:47-80)
+ *   LANE_WITH_CONTINUOUS_SPEED target speed, lane change (-1 / 0 / +1), - (:113-124)
+ * A NaN in the first float means "no action this tick". */
+enum {
+  SMX_ACTION_SPACE_LANE = 0,
+  SMX_ACTION_SPACE_CONTINUOUS = 1,
+  SMX_ACTION_SPACE_ACTUATOR_DYNAMIC = 2,
+  SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED = 3
+};
+
 typedef struct smx_config {
   int32_t num_envs;          /* E: environment instances in this shard            */
   int32_t num_vehicles;      /* N: vehicle slots per instance (<= 64)             */
@@ -102,6 +115,7 @@ typedef struct smx_config {
   double ogm_resolution;
   int32_t lidar_rays;        /* number of rays in smx_lidar_rays                  */
   double lidar_max_distance;
+  int32_t action_space;      /* SMX_ACTION_SPACE_*                                */
 } smx_config;
 
 /* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */
@@ -282,6 +296,9 @@ int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, co
 /* One tick for every env: actions[E*N] are SMX_ACTION_* (int8, device). */
 int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
              const smx_outputs* out, void* hip_stream);
+/* The same tick for the float action spaces: actions[E*N][3] (float32, device). */
+int smx_step_continuous(smx_handle h, const float* actions_dev, const smx_state* st, const smx_spawns* sp,
+                        const smx_outputs* out, void* hip_stream);
 int smx_sync(smx_handle h, void* hip_stream);
 /* Device-side timing: while enabled, every smx_step is bracketed by a hipEvent pair recorded on
  * the stream it is launched on (no synchronisation).  smx_read_step_ms waits for the recorded

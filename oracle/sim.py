@@ -49,6 +49,7 @@ class AgentConfig:
     done_not_moving: bool = False
     not_moving_time: float = 60
     not_moving_distance: float = 1
+    action_space: str = "Lane"  # Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
     ogm: Optional[tuple] = None  # (width, height, resolution) — OGM (agent_interface.py:42-51)
     lidar_rays: Optional[np.ndarray] = None  # base rays [R, 3] (sensors_extra.base_rays)
 
@@ -174,17 +175,37 @@ class OracleEnv:
         for ag, action in zip(self.agents, actions):
             if not ag.alive:
                 continue
-            if action is None or (not isinstance(action, str) and int(action) < 0):
+            space = ag.cfg.action_space
+            none = action is None
+            if not none and space == "Lane" and not isinstance(action, str) and int(action) < 0:
+                none = True
+            if not none and space != "Lane" and np.isnan(float(action[0])):
+                none = True
+            if none:
                 # no action this tick (controllers/__init__.py:87-88): wheel torques last one
                 # physics step only, the steer motor keeps its target
                 ag.body.control(throttle=0.0, brake=0.0, steering=ag.ctrl.steering_state)
                 continue
-            if not isinstance(action, str):
-                action = ctl.LANE_ACTION_NAMES[int(action)]
-            target_speed, lane_change = ctl.LANE_ACTIONS[action]
-            thr, brk, steer = ctl.perform_lane_following(
-                rmap, ag.body, ag.ctrl, self.dt, target_speed=target_speed, lane_change=lane_change, route=()
-            )
+            if space == "Continuous":  # controllers/__init__.py:94-99
+                thr, brk, steer = (float(np.clip(action[0], 0.0, 1.0)), float(np.clip(action[1], 0.0, 1.0)),
+                                   float(np.clip(action[2], -1, 1)))
+                ag.ctrl.steering_state = steer
+            elif space == "ActuatorDynamic":  # actuator_dynamic_controller.py:47-80
+                change = float(np.clip(action[2], -1, 1))
+                p = 0.001
+                steer = float(np.clip((1 - p) * ag.ctrl.steering_state + change * self.dt, -1, 1))
+                thr, brk = float(np.clip(action[0], 0.0, 1.0)), float(np.clip(action[1], 0.0, 1.0))
+                ag.ctrl.steering_state = steer  # last_steering_angle
+            else:
+                if space == "LaneWithContinuousSpeed":  # controllers/__init__.py:113-124
+                    target_speed, lane_change = float(action[0]), int(action[1])
+                else:
+                    if not isinstance(action, str):
+                        action = ctl.LANE_ACTION_NAMES[int(action)]
+                    target_speed, lane_change = ctl.LANE_ACTIONS[action]
+                thr, brk, steer = ctl.perform_lane_following(
+                    rmap, ag.body, ag.ctrl, self.dt, target_speed=target_speed, lane_change=lane_change, route=()
+                )
             ag.body.control(throttle=thr, brake=brk, steering=steer)
         # physics (smarts.py:923-931)
         for ag in self.agents:

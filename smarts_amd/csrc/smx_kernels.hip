@@ -42,6 +42,7 @@ struct KernelArgs {
   smx_spawns sp;
   smx_outputs out;
   const int8_t* actions;
+  const float* actions_f32;  // float action spaces: [E*N][3]
   const uint8_t* env_mask;  // k_reset: explicit mask (NULL = use env_reset_pending / all)
   const double* lidar_rays;
   int first_only;           // restrict to vehicles carrying SMX_F_FIRST (reset observations)
@@ -201,18 +202,59 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   cs.mcl_x = SF(SMX_S_MCL_X);
   cs.mcl_y = SF(SMX_S_MCL_Y);
   cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
-  const int action = a.actions[gid];
+  // ---- Controllers.perform_action (controllers/__init__.py:61-152)
+  const int space = c.action_space;
+  int action = SMX_ACTION_NONE;
+  float act0 = 0.f, act1 = 0.f, act2 = 0.f;
+  bool has_action;
+  if (space == SMX_ACTION_SPACE_LANE) {
+    action = a.actions[gid];
+    has_action = action >= 0;
+  } else {
+    act0 = a.actions_f32[gid * 3 + 0];
+    act1 = a.actions_f32[gid * 3 + 1];
+    act2 = a.actions_f32[gid * 3 + 2];
+    has_action = !(act0 != act0);  // NaN = no action
+  }
   ControlOut co;
   // no action this tick: wheel torques do not persist, the steer motor target does
   co.throttle = 0.0;
   co.brake = 0.0;
   co.steering = cs.steer;
-  if (action >= 0 && !(a.debug_skip & 1)) {  // uniform within a team
-    // Controllers.perform_action, Lane space (controllers/__init__.py:125-144)
-    const double target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
-    const int lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
-    const double hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
-    const double lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+  const bool lane_following =
+      space == SMX_ACTION_SPACE_LANE || space == SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED;
+  if (has_action && !lane_following) {
+    if (space == SMX_ACTION_SPACE_CONTINUOUS) {
+      // :94-99
+      co.throttle = clip_ref((double)act0, 0.0, 1.0);
+      co.brake = clip_ref((double)act1, 0.0, 1.0);
+      co.steering = clip_ref((double)act2, -1.0, 1.0);
+    } else {
+      // ActuatorDynamicController.perform_action (actuator_dynamic_controller.py:47-80): the third
+      // component is a steering *rate*; the held angle is the controller state
+      const double change = clip_ref((double)act2, -1.0, 1.0);
+      co.throttle = clip_ref((double)act0, 0.0, 1.0);
+      co.brake = clip_ref((double)act1, 0.0, 1.0);
+      co.steering = clip_ref((1.0 - 0.001) * cs.steer + change * c.dt, -1.0, 1.0);
+    }
+    cs.steer = co.steering;  // last_steering_angle / the persisting steer target
+  }
+  if (has_action && lane_following && !(a.debug_skip & 1)) {  // uniform within a team
+    double target_speed;
+    int lane_change;
+    double hg, lg;
+    if (space == SMX_ACTION_SPACE_LANE) {
+      // :125-144
+      target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
+      lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
+      hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
+      lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+    } else {
+      // :113-124: (target_speed, lane_change)
+      target_speed = (double)act0;
+      lane_change = (int)act1;
+      lateral_gains_for_speed(target_speed, hg, lg);
+    }
     const PathSeeds seed = load_seeds(a, gid, total);  // found by k_scan at this very pose
     const double px = s.x, py = s.y;
     CtrlPath path;
@@ -1399,6 +1441,8 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) && (size_t)c.wp_paths * c.wp_len * 39 * (SMX_BLOCK / SMX_WP_LANES) > 96 * 1024)
     return fail(h, SMX_ERR_INVALID, "waypoints: wp_paths * wp_len too large for the LDS staging area");
+  if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED)
+    return fail(h, SMX_ERR_INVALID, "unknown action_space");
   if ((c.sensors & SMX_SENSOR_OGM) &&
       (c.ogm_width < 1 || c.ogm_height < 1 || (c.ogm_width * c.ogm_height) % 16 != 0 ||
        c.ogm_width * c.ogm_height > 64 * 1024 || !(c.ogm_resolution > 0.0)))
@@ -1548,13 +1592,16 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   return SMX_OK;
 }
 
-static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint8_t* mask, const smx_state* st,
+static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const float* actions_f32, const uint8_t* mask,
+                   const smx_state* st,
                    const smx_spawns* sp, const smx_outputs* out, void* stream_) {
   if (!h) return SMX_ERR_INVALID;
   if (!h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_load_map has not been called");
   int rc = check_buffers(h, st, sp, out);
   if (rc != SMX_OK) return rc;
-  if (is_step && !actions) return fail(h, SMX_ERR_INVALID, "null actions");
+  if (is_step && !actions && !actions_f32) return fail(h, SMX_ERR_INVALID, "null actions");
+  if (is_step && (h->cfg.action_space == SMX_ACTION_SPACE_LANE) != (actions != nullptr))
+    return fail(h, SMX_ERR_INVALID, "smx_step takes the Lane action space, smx_step_continuous the float ones");
   hipStream_t stream = (hipStream_t)stream_;
   const smx_config& c = h->cfg;
   KernelArgs a;
@@ -1564,6 +1611,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
   a.sp = *sp;
   a.out = *out;
   a.actions = actions;
+  a.actions_f32 = actions_f32;
   a.env_mask = mask;
   a.lidar_rays = h->lidar_rays;
   a.first_only = 0;
@@ -1653,12 +1701,17 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const uint
 
 extern "C" int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, const smx_spawns* sp,
                          const smx_outputs* out, void* hip_stream) {
-  return enqueue(h, false, nullptr, env_mask_dev, st, sp, out, hip_stream);
+  return enqueue(h, false, nullptr, nullptr, env_mask_dev, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
                         const smx_outputs* out, void* hip_stream) {
-  return enqueue(h, true, actions_dev, nullptr, st, sp, out, hip_stream);
+  return enqueue(h, true, actions_dev, nullptr, nullptr, st, sp, out, hip_stream);
+}
+
+extern "C" int smx_step_continuous(smx_handle h, const float* actions_dev, const smx_state* st, const smx_spawns* sp,
+                                   const smx_outputs* out, void* hip_stream) {
+  return enqueue(h, true, nullptr, actions_dev, nullptr, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_sync(smx_handle h, void* hip_stream) {

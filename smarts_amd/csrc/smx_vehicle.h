@@ -112,6 +112,88 @@ __device__ __forceinline__ double curvature_calculation(const Traj10& t, int off
 }
 
 
+// LaneFollowingController.calculate_lateral_gains (lane_following_controller.py:376-437) for an
+// arbitrary target speed (ActionSpaceType.LaneWithContinuousSpeed).  The reference places the poles
+// (-35, -15, -2, -3) of the linearised lateral dynamics with scipy.signal.place_poles; for this
+// single-input system the gain row is unique and equals Ackermann's formula
+// K = e4^T C^-1 phi(A) (agreement with scipy 2e-12 relative, tests/test_host_logic.py), after which
+// both gains are clipped.  The lateral gain is 0.587 at every speed (clipped to 3.4); the heading
+// gain grows linearly and crosses the clip window [0.02, 0.04] between 2.02 and 2.06 m/s.
+__device__ inline void lateral_gains_for_speed(double v, double& heading_gain, double& lateral_gain) {
+  if (!(v > 0.0)) {
+    heading_gain = 0.01;
+    lateral_gain = 0.36;
+    return;
+  }
+  // vehicle.chassis.mass_and_inertia is the chassis link's (chassis.py:575-582, models/vehicle.urdf)
+  const double L = 0.5 * SMX_CHASSIS_LENGTH, M = 2356.0, IZ = 2681.95008628, C = SMX_CORNERING_STIFFNESS;
+  double A[4][4] = {{0.0, v, 0.0, v},
+                    {0.0, 0.0, 1.0, 0.0},
+                    {0.0, 0.0, -(2.0 * C * (L * L)) / (v * IZ), 0.0},
+                    {0.0, 0.0, -1.0, -2.0 * C / (M * v)}};
+  const double B[4] = {0.0, 0.0, L * C / IZ, C / (M * v)};
+  const double poles[4] = {-35.0, -15.0, -2.0, -3.0};
+  // controllability matrix columns B, AB, A^2 B, A^3 B
+  double Cm[4][4];
+  double col[4] = {B[0], B[1], B[2], B[3]};
+  for (int k = 0; k < 4; ++k) {
+    for (int i = 0; i < 4; ++i) Cm[i][k] = col[i];
+    double nxt[4];
+    for (int i = 0; i < 4; ++i) {
+      double acc = 0.0;
+      for (int j = 0; j < 4; ++j) acc += A[i][j] * col[j];
+      nxt[i] = acc;
+    }
+    for (int i = 0; i < 4; ++i) col[i] = nxt[i];
+  }
+  // phi(A) = prod (A - p_i I)
+  double P[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int q = 0; q < 4; ++q) {
+    double T[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < 4; ++k) acc += P[i][k] * (A[k][j] - (k == j ? poles[q] : 0.0));
+        T[i][j] = acc;
+      }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) P[i][j] = T[i][j];
+  }
+  // solve Cm^T x = e4 by Gaussian elimination with partial pivoting
+  double G[4][5];
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) G[i][j] = Cm[j][i];
+    G[i][4] = (i == 3) ? 1.0 : 0.0;
+  }
+  for (int k = 0; k < 4; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < 4; ++i)
+      if (fabs(G[i][k]) > fabs(G[piv][k])) piv = i;
+    for (int j = 0; j < 5; ++j) {
+      const double t = G[k][j];
+      G[k][j] = G[piv][j];
+      G[piv][j] = t;
+    }
+    for (int i = k + 1; i < 4; ++i) {
+      const double f = G[i][k] / G[k][k];
+      for (int j = k; j < 5; ++j) G[i][j] -= f * G[k][j];
+    }
+  }
+  double x[4];
+  for (int i = 3; i >= 0; --i) {
+    double acc = G[i][4];
+    for (int j = i + 1; j < 4; ++j) acc -= G[i][j] * x[j];
+    x[i] = acc / G[i][i];
+  }
+  double K0 = 0.0, K1 = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    K0 += x[i] * P[i][0];
+    K1 += x[i] * P[i][1];
+  }
+  heading_gain = clip_ref(K1, 0.02, 0.04);
+  lateral_gain = clip_ref(K0, 3.4, 4.1);
+}
+
 // The chosen waypoint path of the controller (lookahead 16 => at most 17 waypoints), in registers.
 #define SMX_CTRL_WPS 17
 struct CtrlPath {

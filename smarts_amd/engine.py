@@ -51,6 +51,7 @@ class SimConfig:
     ogm_height: int = 256
     ogm_resolution: float = 50 / 256
     lidar: Optional[SensorParams] = None  # agent_interface.py:132-135
+    action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
 
     def sensors_mask(self) -> int:
         m = 0
@@ -193,6 +194,10 @@ class BatchedSim:
         c.not_moving_time, c.not_moving_distance = cfg.not_moving_time, cfg.not_moving_distance
         c.auto_reset = 1 if cfg.auto_reset else 0
         c.reset_elapsed_steps = cfg.reset_elapsed_steps()
+        if cfg.action_space not in nat.ACTION_SPACES:
+            raise ValueError(f"action space {cfg.action_space!r} is not on the accelerated path "
+                             f"(supported: {sorted(nat.ACTION_SPACES)})")
+        c.action_space = nat.ACTION_SPACES[cfg.action_space]
         if cfg.ogm:
             c.ogm_width, c.ogm_height, c.ogm_resolution = cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution
         if cfg.lidar is not None:
@@ -343,12 +348,21 @@ class BatchedSim:
     def step(self, actions: torch.Tensor) -> Dict[str, torch.Tensor]:
         if not self._was_reset:
             raise RuntimeError("step() before reset()")  # SMARTSNotSetupError (smarts.py:207-208)
-        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
-            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
-        assert actions.shape == (self.E, self.N), actions.shape
-        rc = self.lib.smx_step(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
-                               C.byref(self._out), self._stream_ptr())
-        nat.check(self.lib, self.handle, rc, "smx_step")
+        if self.cfg.action_space == "Lane":
+            if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+                actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+            assert actions.shape == (self.E, self.N), actions.shape
+            rc = self.lib.smx_step(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
+                                   C.byref(self._out), self._stream_ptr())
+            nat.check(self.lib, self.handle, rc, "smx_step")
+        else:
+            # three floats per agent; NaN in the first one = no action this tick
+            if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            assert actions.shape == (self.E, self.N, 3), actions.shape
+            rc = self.lib.smx_step_continuous(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
+                                              C.byref(self._out), self._stream_ptr())
+            nat.check(self.lib, self.handle, rc, "smx_step_continuous")
         return self.out
 
     def set_timing(self, level):

@@ -28,6 +28,11 @@ class ActionSpaceType(Enum):
     Imitation = 9
 
 
+# action spaces with a device controller (include/smx.h SMX_ACTION_SPACE_*)
+DEVICE_ACTION_SPACES = (ActionSpaceType.Lane, ActionSpaceType.Continuous, ActionSpaceType.ActuatorDynamic,
+                        ActionSpaceType.LaneWithContinuousSpeed)
+
+
 @dataclass
 class DrivableAreaGridMap:
     """agent_interface.py:29-38."""
@@ -218,12 +223,13 @@ class AgentInterface:
 
     # ------------------------------------------------------------------ device support
     def validate_for_device(self):
-        """Raise for anything the MI355X path does not implement (the Lane action
-        space and the waypoints / neighbourhood / accelerometer / OGM / lidar sensors)."""
-        if self.action is not ActionSpaceType.Lane:
+        """Raise for anything the MI355X path does not implement (the Lane,
+        Continuous, ActuatorDynamic and LaneWithContinuousSpeed action spaces and the waypoints /
+        neighbourhood / accelerometer / OGM / lidar sensors)."""
+        if self.action not in DEVICE_ACTION_SPACES:
             raise NotImplementedError(
-                f"action space {self.action} is not on the accelerated path (ActionSpaceType.Lane only; "
-                "SURVEY.md §8f-3 lists the others as next)")
+                f"action space {self.action} is not on the accelerated path "
+                f"(supported: {[a.name for a in DEVICE_ACTION_SPACES]})")
         for name in ("road_waypoints", "drivable_area_grid_map", "rgb"):
             if getattr(self, name):
                 raise NotImplementedError(f"AgentInterface.{name} is not on the accelerated path")

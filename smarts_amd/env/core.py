@@ -58,6 +58,19 @@ def encode_lane_action(action: Any) -> int:
     raise TypeError(f"ActionSpaceType.Lane expects a string action, got {type(action).__name__}")
 
 
+def encode_float_action(space: ActionSpaceType, action: Any):
+    """Continuous / ActuatorDynamic: (throttle, brake, steering[-rate]); LaneWithContinuousSpeed:
+    (target_speed, lane_change) (controllers/__init__.py:94-124) -> three float32."""
+    vals = [float(x) for x in action]
+    if space is ActionSpaceType.LaneWithContinuousSpeed:
+        if len(vals) != 2:
+            raise ValueError("LaneWithContinuousSpeed expects (target_speed, lane_change)")
+        vals.append(0.0)
+    elif len(vals) != 3:
+        raise ValueError(f"{space.name} expects three floats")
+    return vals
+
+
 def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: int, dt: float, auto_reset: bool,
                               waypoint_window: Tuple[int, int] = (4, 20)):
     """AgentInterface -> SimConfig (one interface for every agent, as FormatObs also requires,
@@ -75,6 +88,7 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
         done_collision=dc.collision, done_off_road=dc.off_road, done_off_route=dc.off_route,
         done_on_shoulder=dc.on_shoulder, done_wrong_way=dc.wrong_way, done_not_moving=dc.not_moving,
         not_moving_time=evc.not_moving_time, not_moving_distance=evc.not_moving_distance, auto_reset=auto_reset,
+        action_space=itf.action.name,
     )
     if itf.waypoints:
         # the dense rows keep the StdObs window (format_obs.py:42) unless the lookahead is shorter
@@ -141,13 +155,22 @@ class BatchCore:
 
     # ------------------------------------------------------------------ object path
     def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
-        acts = np.full((self.E, self.N), NO_ACTION, dtype=np.int8)
+        space = self.interface.action
+        lane = space is ActionSpaceType.Lane
+        if lane:
+            acts = np.full((self.E, self.N), NO_ACTION, dtype=np.int8)
+        else:
+            acts = np.full((self.E, self.N, 3), np.nan, dtype=np.float32)  # NaN = no action
         for e, agent_actions in enumerate(per_env_actions):
             assert isinstance(agent_actions, dict) and all(isinstance(k, str) for k in agent_actions), \
                 "Expected Dict[str, any]"  # hiway_env.py:232-234
             for agent_id, action in agent_actions.items():
-                spec = self.agent_specs[agent_id]
-                acts[e, self.agent_ids.index(agent_id)] = encode_lane_action(spec.action_adapter(action))
+                adapted = self.agent_specs[agent_id].action_adapter(action)
+                i = self.agent_ids.index(agent_id)
+                if lane:
+                    acts[e, i] = encode_lane_action(adapted)
+                else:
+                    acts[e, i] = encode_float_action(space, adapted)
         return acts
 
     def host_rows(self, out) -> Dict[str, np.ndarray]:

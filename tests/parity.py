@@ -22,6 +22,7 @@ def oracle_config(cfg):
         done_not_moving=cfg.done_not_moving,
         not_moving_time=cfg.not_moving_time,
         not_moving_distance=cfg.not_moving_distance,
+        action_space=cfg.action_space,
         ogm=(cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution) if cfg.ogm else None,
         lidar_rays=oracle_lidar_rays(cfg.lidar) if cfg.lidar is not None else None,
     )

@@ -35,7 +35,11 @@ def test_agent_interface_presets_follow_the_reference():
 
 def test_unsupported_interfaces_fail_loudly():
     with pytest.raises(NotImplementedError):
-        AgentInterface.from_type(AgentType.Full).validate_for_device()
+        AgentInterface.from_type(AgentType.Full).validate_for_device()  # rgb / dagm
+    with pytest.raises(NotImplementedError):
+        AgentInterface.from_type(AgentType.Tracker).validate_for_device()  # Trajectory action space
+    for t in (AgentType.Standard, AgentType.StandardWithAbsoluteSteering, AgentType.LanerWithSpeed, AgentType.Loner):
+        AgentInterface.from_type(t).validate_for_device()
     with pytest.raises(NotImplementedError):
         AgentInterface.from_type(AgentType.Laner, rgb=True).validate_for_device()
     AgentInterface.from_type(AgentType.Laner, ogm=True, lidar=True, neighborhood_vehicles=True).validate_for_device()
@@ -65,6 +69,14 @@ def test_lane_action_encoding():
         env_core.encode_lane_action("fly")
     with pytest.raises(TypeError):
         env_core.encode_lane_action(3)
+
+
+def test_float_action_encoding():
+    A = ActionSpaceType
+    assert env_core.encode_float_action(A.Continuous, (0.5, 0.0, -0.25)) == [0.5, 0.0, -0.25]
+    assert env_core.encode_float_action(A.LaneWithContinuousSpeed, (12.0, -1)) == [12.0, -1.0, 0.0]
+    with pytest.raises(ValueError):
+        env_core.encode_float_action(A.ActuatorDynamic, (0.1, 0.2))
 
 
 def test_scenario_resolution():

@@ -90,6 +90,36 @@ def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps)
     sim.close()
 
 
+@pytest.mark.parametrize("space,name,E,N,T,seed", [("Continuous", "loop", 4, 8, 40, 41), ("ActuatorDynamic", "4lane", 2, 16, 30, 42),
+                                                  ("LaneWithContinuousSpeed", "loop", 4, 8, 50, 43),
+                                                  ("LaneWithContinuousSpeed", "minicity", 2, 16, 25, 44)])
+def test_float_action_spaces(space, name, E, N, T, seed, nets, compiled_maps):
+    """Controllers.perform_action for Continuous / ActuatorDynamic / LaneWithContinuousSpeed
+    (controllers/__init__.py:94-124), teacher-forced against the oracle; target speeds include the
+    clip window of the heading gain (2.02-2.06 m/s) and 0."""
+    import torch
+
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, action_space=space)
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(seed)
+    for t in range(T):
+        if space == "LaneWithContinuousSpeed":
+            speed = rng.choice([0.0, 2.03, 2.045, 5.0, 9.5, 14.0, 18.0], size=(E, N))
+            change = rng.choice([0.0, 0.0, 0.0, 1.0, -1.0], size=(E, N))
+            acts = np.stack([speed, change, np.zeros((E, N))], axis=-1).astype(np.float32)
+        else:
+            acts = np.stack([rng.uniform(-0.2, 1.2, (E, N)), np.where(rng.random((E, N)) < 0.2, rng.uniform(0, 1, (E, N)), 0.0),
+                             rng.uniform(-1.3, 1.3, (E, N)) * 0.3], axis=-1).astype(np.float32)
+        if t % 5 == 2:
+            acts[0, 0, 0] = np.nan  # an agent that sends no action this tick
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts.astype(np.float64))
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{space} {name} t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 

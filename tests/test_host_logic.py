@@ -118,3 +118,42 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_ackermann_formula_reproduces_place_poles():
+    """smx_vehicle.h lateral_gains_for_speed: the reference places poles with scipy
+    (lane_following_controller.py:391-430); for this single-input system the gain row is unique and
+    Ackermann's formula gives it.  Checked across the clip window of the heading gain."""
+    import warnings
+
+    from scipy import signal
+
+    from oracle import controller as ctl
+    from oracle import dynamics as dyn
+
+    L, M, IZ, C = dyn.CHASSIS_LENGTH / 2, dyn.CHASSIS_MASS, dyn.CHASSIS_INERTIA_Z, dyn.ROAD_STIFFNESS
+    assert (M, IZ, C) == (2356.0, 2681.95008628, 100000.0)  # the literals in smx_vehicle.h
+    poles = np.array(ctl.DESIRED_POLES, dtype=float)
+
+    def mats(v):
+        A = np.array([[0, v, 0, v], [0, 0, 1, 0], [0, 0, -(2 * C * L ** 2) / (v * IZ), 0], [0, 0, -1, -2 * C / (M * v)]])
+        B = np.array([[0], [0], [L * C / IZ], [C / (M * v)]])
+        return A, B
+
+    def ackermann(v):
+        A, B = mats(v)
+        Cm = np.hstack([B, A @ B, A @ A @ B, A @ A @ A @ B])
+        phi = np.eye(4)
+        for p in poles:
+            phi = phi @ (A - p * np.eye(4))
+        return np.linalg.solve(Cm.T, np.array([0, 0, 0, 1.0])) @ phi
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for v in (0.3, 1.0, 2.0, 2.02, 2.03, 2.04, 2.06, 3.0, 8.0, 15.0, 30.0):
+            A, B = mats(v)
+            K = signal.place_poles(A, B, poles, method="KNV0").gain_matrix[0]
+            Ka = ackermann(v)
+            assert abs(K[0] - Ka[0]) <= 1e-9 * abs(K[0]) and abs(K[1] - Ka[1]) <= 1e-9 * max(abs(K[1]), 1e-3)
+            h, l = ctl.lateral_gains(v, L, M, IZ, C)
+            assert l == 3.4 and h == np.clip(Ka[1], 0.02, 0.04) or abs(h - np.clip(Ka[1], 0.02, 0.04)) < 1e-11
