@@ -114,6 +114,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             f"{path} not found: build it with `python -m smarts_amd.build` (hipcc --offload-arch=gfx950); "
             "smarts_amd has no CPU fallback"
         )
+    # PyTorch-ROCm ships its own HIP runtime; the device buffers come from it, so it has to be the
+    # one this library binds to.  Loading torch first makes the dynamic linker resolve
+    # libamdhip64 to torch's copy (loading this library first would bring up a second runtime that
+    # sees no device).
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(path)
     except OSError as e:  # pragma: no cover - depends on the box
