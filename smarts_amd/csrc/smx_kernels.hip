@@ -1439,8 +1439,6 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
-  if ((c.sensors & SMX_SENSOR_WAYPOINTS) && (size_t)c.wp_paths * c.wp_len * 39 * (SMX_BLOCK / SMX_WP_LANES) > 96 * 1024)
-    return fail(h, SMX_ERR_INVALID, "waypoints: wp_paths * wp_len too large for the LDS staging area");
   if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED)
     return fail(h, SMX_ERR_INVALID, "unknown action_space");
   if ((c.sensors & SMX_SENSOR_OGM) &&

@@ -120,6 +120,49 @@ def test_float_action_spaces(space, name, E, N, T, seed, nets, compiled_maps):
     sim.close()
 
 
+VARIANTS = {
+    "no_waypoints_sensor": dict(waypoints=False),                       # trip meter from the lookahead-1 query (sensors.py:270-275)
+    "no_accelerometer_unlimited_radius": dict(accelerometer=False, nb_radius=None),
+    "short_lookahead_two_paths": dict(wp_lookahead=8, wp_paths=2, wp_len=9),
+    "long_rows": dict(wp_lookahead=32, wp_paths=6, wp_len=33),
+    "all_done_criteria": dict(done_on_shoulder=True, done_wrong_way=True, done_not_moving=True, not_moving_time=0.5,
+                              not_moving_distance=1.0, done_collision=False, max_episode_steps=15),
+    "half_timestep": dict(dt=0.05),
+    "no_neighbours": dict(neighbors=False),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("name,E,N", [("loop", 3, 7), ("minicity", 1, 64)])
+def test_config_variants(variant, name, E, N, nets, compiled_maps):
+    """Sensor / done-criteria / shape options of AgentInterface (agent_interface.py:214-297) and odd
+    batch shapes (E*N not a multiple of the workgroup, the 64-vehicle limit), teacher-forced."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps(name)
+    kw = dict(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0)
+    kw.update(VARIANTS[variant])
+    cfg = SimConfig(**kw)
+    spawns = make_spawns(cm, E, N, episodes=2, seed=77)
+    sim = BatchedSim(cm, cfg, spawns=spawns)
+    ob = parity.OracleBatch(nets(name), cm, cfg, spawns[0])
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(77)
+    T = 8 if N == 64 else 18
+    for t in range(T):
+        acts = _actions(rng, E, N)
+        if variant == "all_done_criteria":
+            acts[:, ::2] = 1  # slow_down: half of the fleet stops and trips not_moving
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{variant} {name} t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 
