@@ -163,10 +163,11 @@ def main():
 
     def tick(i):
         o = sim.step(actions[i % ACTION_CYCLE])
-        gather(o["reward"], o["done"])
+        gather.start(o["reward"], o["done"])  # learner-side block; overlaps the next tick
 
     for i in range(args.warmup):
         tick(i)
+    gather.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,6 +175,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         tick(args.warmup + i)
+    gather.finish()  # every tick's gather has landed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -57,19 +57,47 @@ def init_process_group(backend: Optional[str] = None):
 class RewardDoneGather:
     """Per-tick gather of the learner-facing block: reward (f32) and done (u8) of every agent of
     every shard, packed as one f32 tensor ``[2, E_shard * N]`` so that it is ONE small collective
-    (C4: 4096 x 32 agents x 8 B = 1 MB node-wide).  Requires equal shard sizes (all_gather)."""
+    (C4: 4096 x 32 agents x 8 B = 1 MB node-wide).  Requires equal shard sizes (all_gather).
+
+    The collective is off the simulation's critical path: ``start`` packs the block on the current
+    stream and launches the all-gather asynchronously (RCCL runs it on its own stream, ordered after
+    the packing), so the next tick's kernels do not wait for it; two buffer pairs alternate, and a
+    pair is waited for only before it is reused two ticks later or when ``result`` is asked for.
+    ``__call__`` = ``start`` + ``result`` (synchronous form)."""
 
     def __init__(self, num_envs: int, num_vehicles: int, device, world_size: int):
         self.world = world_size
         self.n = num_envs * num_vehicles
-        self.send = torch.zeros((2, self.n), dtype=torch.float32, device=device)
-        self.recv = torch.zeros((world_size, 2, self.n), dtype=torch.float32, device=device)
+        self.send = [torch.zeros((2, self.n), dtype=torch.float32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((world_size, 2, self.n), dtype=torch.float32, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0  # pair used by the latest start()
+
+    def _wait(self, k: int):
+        if self.work[k] is not None:
+            self.work[k].wait()  # NCCL: makes the current stream wait; gloo: blocks the host
+            self.work[k] = None
+
+    def start(self, reward: torch.Tensor, done: torch.Tensor) -> None:
+        k = self.k ^ 1
+        self._wait(k)  # the gather launched two ticks ago on this pair
+        self.send[k][0].copy_(reward.reshape(-1))
+        self.send[k][1].copy_(done.reshape(-1))
+        if self.world > 1:
+            self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
+        else:
+            self.recv[k][0].copy_(self.send[k])
+        self.k = k
+
+    def result(self) -> torch.Tensor:
+        """``[world, 2, E_shard * N]`` of the latest ``start`` (waits for it)."""
+        self._wait(self.k)
+        return self.recv[self.k]
+
+    def finish(self) -> None:
+        self._wait(0)
+        self._wait(1)
 
     def __call__(self, reward: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
-        self.send[0].copy_(reward.reshape(-1))
-        self.send[1].copy_(done.reshape(-1))
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
-        else:
-            self.recv[0].copy_(self.send)
-        return self.recv
+        self.start(reward, done)
+        return self.result()

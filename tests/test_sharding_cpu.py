@@ -45,8 +45,15 @@ def _worker(rank, world, port, q):
     g = RewardDoneGather(E, N, "cpu", world)
     reward = torch.arange(E * N, dtype=torch.float64).reshape(E, N) + 100 * rank
     done = ((torch.arange(E * N) + rank) % 2).to(torch.uint8).reshape(E, N)
-    out = g(reward, done)
-    q.put((rank, out.clone().numpy()))
+    out = g(reward, done).clone()
+    # pipelined form: three ticks in flight over the two buffer pairs, results read one tick late
+    seen = []
+    for t in range(3):
+        g.start(reward + t, done)
+        seen.append(g.result()[:, 0, 0].clone())
+    g.finish()
+    assert all(float(seen[t][src]) == t + 100 * src for t in range(3) for src in range(world))
+    q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
