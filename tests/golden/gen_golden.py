@@ -468,6 +468,90 @@ def dump_std_obs():
     return out
 
 
+def dump_sensors(nets):
+    """Reference sensor classes driven directly: AccelerometerSensor
+    (sensors.py:1046-1087), DrivenPathSensor + Sensors._vehicle_is_not_moving (:830-877, :511-525),
+    TripMeterSensor on the reference's own road network (:880-947) and
+    Sensors._vehicle_is_wrong_way (:581-586) over Lane.center_pose_at_point."""
+    from unittest.mock import Mock
+
+    from smarts.core.coordinates import Heading, Point, Pose
+    from smarts.core.sensors import AccelerometerSensor, DrivenPathSensor, Sensors, TripMeterSensor
+
+    out = {}
+    rng = np.random.default_rng(11)
+    # ---- accelerometer
+    acc = AccelerometerSensor(None)
+    lv, av = rng.normal(size=(8, 3)), rng.normal(size=(8, 3))
+    out["acc_lv"], out["acc_av"] = lv, av
+    out["acc_out"] = np.array([np.concatenate(acc(lv[i], av[i], 0.1)) for i in range(8)])
+    # ---- driven path / not moving: 3 s of motion, then creeping, window 2 s, threshold 1 m
+    veh = Mock()
+    sim = Mock()
+    dp = DrivenPathSensor(veh, max_path_length=500)
+    veh.driven_path_sensor = dp
+    pos = np.zeros(2)
+    xs, ys, ts, dist, flag = [], [], [], [], []
+    for t in range(80):
+        step = 0.9 if t < 30 else (0.04 if t < 60 else 0.06)
+        pos = pos + step * np.array([math.cos(0.02 * t), math.sin(0.02 * t)])
+        veh.position = np.array([pos[0], pos[1], 0.0])
+        sim.elapsed_sim_time = round((t + 2) * 0.1, 3)
+        dp.track_latest_driven_path(sim)
+        xs.append(pos[0]); ys.append(pos[1]); ts.append(sim.elapsed_sim_time)
+        dist.append(float(dp.distance_travelled(sim, last_n_seconds=2.0)))
+        flag.append(bool(Sensors._vehicle_is_not_moving(sim, veh, 2.0, 1.0)))
+    out["dp_x"], out["dp_y"], out["dp_t"] = np.array(xs), np.array(ys), np.array(ts)
+    out["dp_dist"], out["dp_not_moving"] = np.array(dist), np.array(flag)
+    # ---- trip meter on scenarios/loop: forward along a lane, a sideways hop, a reverse hop
+    rn = make_reference_road_network(nets["loop"])
+    lane = rn.lane_by_id(sorted(l.getID() for l in nets["loop"].all_lanes() if not l.getID().startswith(":"))[0])
+    poses = []
+    for k in range(24):
+        off = 5.0 + 1.3 * k
+        if k == 17:
+            off -= 4.0  # one step backwards
+        p = lane.from_lane_coord(__import__("smarts.core.coordinates", fromlist=["RefLinePoint"]).RefLinePoint(s=off, t=0.9 if k in (9, 10) else 0.0))
+        vec = lane.vector_at_offset(off)
+        h = math.atan2(vec[1], vec[0]) - math.pi / 2
+        poses.append((float(p.x), float(p.y), float((h + math.pi) % (2 * math.pi) - math.pi)))
+    vehicle = Mock()
+    vehicle.length = 3.68
+    plan = Mock()
+    plan.mission.has_fixed_route = False
+    tsim = Mock()
+    tsim.road_map = rn
+    x0, y0, h0 = poses[0]
+    vehicle.pose = Pose.from_center((x0, y0, 0), Heading(h0))
+    tm = TripMeterSensor(vehicle, tsim, plan)
+    first = tm._wps_for_distance[0] if tm._wps_for_distance else None
+    out["trip_poses"] = np.array(poses)
+    out["trip_first_wp"] = np.array([first.pos[0], first.pos[1], float(first.heading)]) if first else np.zeros(0)
+    totals, incs = [], []
+    for (x, y, h) in poses:
+        wps = rn.waypoint_paths(Pose.from_center((x, y, 0), Heading(h)), lookahead=32, route=None)
+        tm.append_waypoint_if_new(wps[0][0])
+        totals.append(float(tm()))
+        incs.append(float(tm(increment=True)))
+    out["trip_total"], out["trip_inc"] = np.array(totals), np.array(incs)
+    # ---- wrong way
+    for name, net in nets.items():
+        rn = make_reference_road_network(net) if name != "loop" else rn
+        ps = sample_poses(net, np.random.default_rng(5), 120, heading_noise=2.0)
+        rows = []
+        for (x, y, h) in ps:
+            lane = rn.nearest_lane(Point(x, y, 0), radius=7.0)
+            if lane is None or lane.in_junction:
+                continue
+            v = Mock()
+            v.pose = Pose.from_center((x, y, 0), Heading(h))
+            target = lane.center_pose_at_point(Point(x, y, 0)).heading
+            rows.append((x, y, h, float(target), float(bool(Sensors._vehicle_is_wrong_way(v, lane)))))
+        out[f"ww_{name}"] = np.array(rows)
+        out[f"ww_{name}_lanes"] = np.array([rn.nearest_lane(Point(r[0], r[1], 0), radius=7.0).lane_id for r in rows])
+    return out
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -479,7 +563,11 @@ def main():
     if os.environ.get("GOLDEN_ONLY", "") in ("", "stdobs"):
         np.savez_compressed(os.path.join(OUT, "std_obs.npz"), **dump_std_obs())
         print("std obs written")
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "sensors"):
+        nets = {n: load_net(os.path.join(REF, rel)) for n, rel in SCENARIOS.items()}
+        np.savez_compressed(os.path.join(OUT, "sensors.npz"), **dump_sensors(nets))
+        print("sensor goldens written")
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

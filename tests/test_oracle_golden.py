@@ -158,3 +158,77 @@ def test_lidar_base_rays_match_reference():
         assert np.abs(ora - ref).max() < 1e-13  # the dump stores (direction + origin) - origin
         assert np.abs(base_rays(params) - ref).max() < 1e-13
         assert np.allclose(np.linalg.norm(ref, axis=1), params.max_distance, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# sensors: the reference's AccelerometerSensor / DrivenPathSensor / TripMeterSensor /
+# Sensors._vehicle_is_wrong_way run by gen_golden.py (tests/golden/sensors.npz)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sensor_golden():
+    return np.load(os.path.join(GOLDEN, "sensors.npz"))
+
+
+def test_accelerometer_matches_reference(sensor_golden):
+    from collections import deque
+
+    from oracle.sim import OracleEnv
+
+    g = sensor_golden
+    ag = types.SimpleNamespace(linear_velocities=deque(maxlen=3), angular_velocities=deque(maxlen=3))
+    env = types.SimpleNamespace(dt=0.1)
+    for i in range(len(g["acc_lv"])):
+        r = OracleEnv._accelerometer(env, ag, g["acc_lv"][i], g["acc_av"][i])
+        got = np.concatenate([r["linear_acceleration"], r["angular_acceleration"], r["linear_jerk"], r["angular_jerk"]])
+        assert np.array_equal(got, g["acc_out"][i]), i
+
+
+def test_not_moving_matches_reference(sensor_golden):
+    from collections import deque
+
+    from oracle.sim import AgentConfig, OracleEnv
+
+    g = sensor_golden
+    ag = types.SimpleNamespace(cfg=AgentConfig(not_moving_time=2.0, not_moving_distance=1.0), driven_path=deque(maxlen=500))
+    flips = 0
+    for i in range(len(g["dp_t"])):
+        env = types.SimpleNamespace(elapsed_sim_time=float(g["dp_t"][i]))
+        ag.driven_path.append((env.elapsed_sim_time, np.array([g["dp_x"][i], g["dp_y"][i]])))
+        got = OracleEnv._not_moving(env, ag)
+        assert got == bool(g["dp_not_moving"][i]), i
+        flips += int(got)
+    assert 0 < flips < len(g["dp_t"])  # the sequence exercises both outcomes
+
+
+def test_trip_meter_matches_reference(sensor_golden, oracle_maps):
+    from oracle.sim import OracleEnv
+
+    g = sensor_golden
+    rmap = oracle_maps("loop")
+    poses = g["trip_poses"]
+    # TripMeterSensor.__init__: first waypoint of waypoint_paths(pose, lookahead=1, within_radius=length)
+    first = rmap.waypoint_paths(np.array([poses[0][0], poses[0][1], 0.0]), poses[0][2], lookahead=1, within_radius=3.68)[0][0]
+    assert np.array_equal(np.array([first.pos[0], first.pos[1], float(first.heading)]), g["trip_first_wp"])
+    ag = types.SimpleNamespace(wps_for_distance=[first], dist_travelled=0.0, last_dist_travelled=0.0)
+    for k, (x, y, h) in enumerate(poses):
+        wp = rmap.waypoint_paths(np.array([x, y, 0.0]), h, lookahead=32, route=None)[0][0]
+        OracleEnv._append_waypoint_if_new(None, ag, wp)
+        assert ag.dist_travelled == g["trip_total"][k], k
+        assert ag.dist_travelled - ag.last_dist_travelled == g["trip_inc"][k], k
+    assert g["trip_inc"].min() < 0 < g["trip_inc"].max()  # the reverse hop counts negative
+
+
+@pytest.mark.parametrize("name", ["loop", "4lane", "minicity"])
+def test_wrong_way_matches_reference(name, sensor_golden, oracle_maps):
+    from oracle import ref_math as rm
+
+    g = sensor_golden
+    rmap = oracle_maps(name)
+    rows, lanes = g[f"ww_{name}"], g[f"ww_{name}_lanes"]
+    assert len(rows) > 25 and 0 < rows[:, 4].sum() < len(rows)
+    for (x, y, h, target, wrong), lane_id in zip(rows, lanes):
+        lane = rmap.nearest_lane((x, y, 0.0), radius=7.0)
+        assert lane.lane_id == str(lane_id)
+        t = lane.center_pose_heading_at_point((x, y, 0.0))
+        assert t == target
+        assert bool(np.fabs(rm.heading_relative_to(h, t)) > 0.5 * np.pi) == bool(wrong)
