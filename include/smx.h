@@ -116,6 +116,15 @@ typedef struct smx_config {
   int32_t lidar_rays;        /* number of rays in smx_lidar_rays                  */
   double lidar_max_distance;
   int32_t action_space;      /* SMX_ACTION_SPACE_*                                */
+  /* Scripted social traffic (stands in for the SUMO provider on fixed-vehicle-count scenarios,
+   * smarts.py:868-921, chassis.py:187-320 BoxChassis): the LAST num_social slots of every env
+   * are kinematic lane followers.  They move along their lane's centre line at
+   * social_speed_factor x the lane's speed limit, continue onto outgoing lane
+   * (slot + lanes crossed) mod #outgoing, are seen by every sensor and collision test, and
+   * produce no observation of their own.  State reuse: SMX_S_MCL_X = lane, SMX_S_MCL_Y =
+   * arclength offset, SMX_S_SPD_INT = lanes crossed. */
+  int32_t num_social;
+  double social_speed_factor;
 } smx_config;
 
 /* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */
@@ -201,7 +210,8 @@ enum {
   SMX_F_MCL_SET = 1 << 1,
   SMX_F_TRIP_HAS_WP = 1 << 2,
   SMX_F_HIST_SHIFT = 3, /* bits 3-4: accelerometer samples held (0..2) */
-  SMX_F_FIRST = 1 << 5  /* vehicle was just (re)created: its next observation is a reset observation */
+  SMX_F_FIRST = 1 << 5, /* vehicle was just (re)created: its next observation is a reset observation */
+  SMX_F_SOCIAL = 1 << 6 /* scripted social vehicle (no controller, no observation) */
 };
 
 #define SMX_DRIVEN_PATH_LEN 500 /* DrivenPathSensor deque, sensors.py:838 */
@@ -234,6 +244,7 @@ enum { SMX_FACT_ON_ROAD = 1 << 0, SMX_FACT_CORNER_SHIFT = 1 /* bits 1-4: corner 
 typedef struct smx_spawns {
   int32_t episodes;
   const double* pose; /* device, [episodes][E*N][4] = x, y, heading, speed */
+  const double* social; /* device, [episodes][E*N][2] = lane, arclength offset (social slots only; NULL if none) */
 } smx_spawns;
 
 /* ---- per-tick outputs, caller-owned device memory, dense StdObs layout

@@ -136,11 +136,77 @@ def boxes_within(a, b, leeway):
     return False
 
 
-class OracleEnv:
-    """One SMARTS instance with N ego agents on one map."""
+class SocialBody(VehicleBody):
+    """Scripted social vehicle (the model of include/smx.h ``smx_config.num_social``; stands in for
+    the SUMO provider's BoxChassis vehicles, smarts.py:868-921 — parity with SUMO itself is unpinned):
+    follows its lane's centre line at ``factor`` x the speed limit, continues on outgoing lane
+    ``(slot + lanes crossed) mod #outgoing``, stops at the end of a lane without successors."""
 
-    def __init__(self, road_map, spawns, configs, dt=0.1):
-        """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre)."""
+    def __init__(self, x, y, heading, speed, lane, offset, slot, factor):
+        super().__init__(x, y, heading, speed)
+        self.lane, self.offset, self.slot, self.factor, self.crossed = lane, float(offset), slot, factor, 0
+
+    @staticmethod
+    def _cum(lane):
+        acc, cum = 0.0, [0.0]
+        for a, b in zip(lane.shape[:-1], lane.shape[1:]):
+            ex, ey = float(a[0] - b[0]), float(a[1] - b[1])
+            acc = acc + math.sqrt(ex * ex + ey * ey)
+            cum.append(acc)
+        return cum
+
+    def control(self, *a, **k):
+        pass
+
+    def step(self, dt):
+        speed = self.lane.speed_limit * self.factor
+        self.offset += speed * dt
+        for _ in range(64):
+            L = self._cum(self.lane)[-1]
+            if self.offset < L:
+                break
+            outs = self.lane.outgoing_lanes
+            if not outs:
+                self.offset, speed = L, 0.0
+                break
+            self.offset -= L
+            self.lane = outs[(self.slot + self.crossed) % len(outs)]
+            self.crossed += 1
+        shape, cum = self.lane.shape, self._cum(self.lane)
+        seg = len(shape) - 2
+        for v in range(len(shape) - 1):
+            if cum[v] + self._seg_len(shape, v) > self.offset:
+                seg = v
+                break
+        a, b = shape[seg], shape[seg + 1]
+        ln = self._seg_len(shape, seg)
+        along = min(max(self.offset - cum[seg], 0.0), ln)
+        f = along / ln if ln > 0.0 else 0.0
+        self.x = a[0] + (b[0] - a[0]) * f
+        self.y = a[1] + (b[1] - a[1]) * f
+        self.heading = rm.wrap_heading(math.atan2(b[1] - a[1], b[0] - a[0]) - 0.5 * math.pi)
+        self.u, self.v, self.yaw_rate_z = speed, 0.0, 0.0
+
+    @staticmethod
+    def _seg_len(shape, v):
+        ex, ey = float(shape[v][0] - shape[v + 1][0]), float(shape[v][1] - shape[v + 1][1])
+        return math.sqrt(ex * ex + ey * ey)
+
+
+class _Social:
+    alive = True
+    collisions = ()
+
+    def __init__(self, body):
+        self.body = body
+
+
+class OracleEnv:
+    """One SMARTS instance with N ego agents (and optional scripted social vehicles) on one map."""
+
+    def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8):
+        """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre) for the agents followed
+        by the social vehicles; ``social``: (lane id, arclength offset) per social vehicle."""
         self.road_map = road_map
         self.dt = dt
         self._round = rm.round_param_for_dt(dt)
@@ -151,14 +217,22 @@ class OracleEnv:
         for _ in range(self.reset_steps):
             self.elapsed_sim_time = round(self.elapsed_sim_time + dt, self._round)
         self.step_count = self.reset_steps - 1
-        self.agents = [
-            _Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(np.asarray(spawns, dtype=np.float64), configs)
+        spawns = np.asarray(spawns, dtype=np.float64)
+        n_agents = len(spawns) - len(social)
+        self.agents = [_Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(spawns[:n_agents], configs)]
+        self.social = [
+            _Social(SocialBody(*spawns[n_agents + k], road_map.lane_by_id(lane_id), off, n_agents + k, social_speed_factor))
+            for k, (lane_id, off) in enumerate(social)
         ]
+
+    def _vehicles(self):
+        """(slot, body) of every vehicle in the world, agents first (the vehicle-index order)."""
+        return [(j, v.body) for j, v in enumerate(list(self.agents) + list(self.social)) if v.alive]
 
     def reset_observe(self):
         """The observations ``SMARTS.reset`` returns: sensors run on the just-created vehicles
         (no controller, no physics yet)."""
-        alive_states = [(j, a.body) for j, a in enumerate(self.agents) if a.alive]
+        alive_states = self._vehicles()
         obs = {}
         for i, ag in enumerate(self.agents):
             ag.steps += 1
@@ -211,18 +285,21 @@ class OracleEnv:
         for ag in self.agents:
             if ag.alive:
                 ag.body.step(self.dt)
+        for sv in self.social:
+            sv.body.step(self.dt)
         # collisions (smarts.py:1270-1291)
+        everyone = self._vehicles()
         for i, ag in enumerate(self.agents):
             ag.collisions = []
             if not ag.alive:
                 continue
-            for j, other in enumerate(self.agents):
-                if j == i or not other.alive:
+            for j, other in everyone:
+                if j == i:
                     continue
-                if boxes_within(ag.body, other.body, COLLISION_LEEWAY):
+                if boxes_within(ag.body, other, COLLISION_LEEWAY):
                     ag.collisions.append(j)
         # sensors + observe (smarts.py:287-301)
-        alive_states = [(j, a.body) for j, a in enumerate(self.agents) if a.alive]
+        alive_states = everyone
         obs, rewards, dones = {}, {}, {}
         for i, ag in enumerate(self.agents):
             if not ag.alive:

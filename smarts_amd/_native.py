@@ -30,7 +30,7 @@ STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT
                 "LV1_LAT", "AV1_Z", "PATH_SUM", "PREV_X", "PREV_Y"]
 S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
-F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST = 1, 2, 4, 3, 32
+F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST, F_SOCIAL = 1, 2, 4, 3, 32, 64
 FACT_I_COUNT, FACT_F_COUNT = 4, 2
 DRIVEN_PATH_LEN = 500
 SEED_COUNT = 9
@@ -50,7 +50,7 @@ class SmxConfig(C.Structure):
         ("nb_max", _i32), ("nb_radius", _f64), ("max_episode_steps", _i32), ("not_moving_time", _f64),
         ("not_moving_distance", _f64), ("auto_reset", _i32), ("reset_elapsed_steps", _i32),
         ("ogm_width", _i32), ("ogm_height", _i32), ("ogm_resolution", _f64), ("lidar_rays", _i32),
-        ("lidar_max_distance", _f64), ("action_space", _i32),
+        ("lidar_max_distance", _f64), ("action_space", _i32), ("num_social", _i32), ("social_speed_factor", _f64),
     ]
 
 
@@ -76,7 +76,7 @@ class SmxState(C.Structure):
 
 
 class SmxSpawns(C.Structure):
-    _fields_ = [("episodes", _i32), ("pose", _p)]
+    _fields_ = [("episodes", _i32), ("pose", _p), ("social", _p)]
 
 
 OUTPUT_FIELDS = [

@@ -191,6 +191,23 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
+  if (flags & SMX_F_SOCIAL) {  // scripted lane follower: no controller, no dynamics
+    if (p0 != 0) return;
+    int lane = (int)SF(SMX_S_MCL_X), crossed = (int)SF(SMX_S_SPD_INT);
+    double offset = SF(SMX_S_MCL_Y), speed, x, y, heading;
+    SF(SMX_S_PREV_X) = SF(SMX_S_X);
+    SF(SMX_S_PREV_Y) = SF(SMX_S_Y);
+    social_step(m, (int)(gid % c.num_vehicles), c.social_speed_factor, c.dt, lane, offset, crossed, speed);
+    social_pose(m, lane, offset, x, y, heading);
+    SF(SMX_S_X) = x;
+    SF(SMX_S_Y) = y;
+    SF(SMX_S_HEADING) = heading;
+    SF(SMX_S_U) = speed;
+    SF(SMX_S_MCL_X) = (double)lane;
+    SF(SMX_S_MCL_Y) = offset;
+    SF(SMX_S_SPD_INT) = (double)crossed;
+    return;
+  }
   SMX_TSTAMP(tc0);
   VehState s = load_vehicle(a, gid, total);
   CtrlState cs;
@@ -457,13 +474,14 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
       cx[q] = s.x + ch * (qx - s.x) + sh * (qy - s.y);
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
-    RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), 4, cx, cy);
+    const bool social = (flags & SMX_F_SOCIAL) != 0;  // only its nearest lane is ever asked for (neighbour rows)
+    RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), social ? 0 : 4, cx, cy);
     SMX_TSTAMP(ts1);
     SMX_TACC(10, ts0, ts1);
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
     // nearest lane closest to the vehicle; junction lanes are exempt (:548-551)
     double lane_heading = 0.0;
-    const bool want_heading = h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
+    const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
     if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
     SMX_TSTAMP(ts2);
     SMX_TACC(11, ts1, ts2);
@@ -477,6 +495,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
     return;
   }
   // ---- path seeds
+  if (flags & SMX_F_SOCIAL) return;
   SMX_TSTAMP(ts3);
   Top10 t;
   team_nearest10(m, s.x, s.y, t);
@@ -569,7 +588,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
   const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
-  if (!(flags & SMX_F_ALIVE) || (a.first_only && !(flags & SMX_F_FIRST))) return;
+  if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   const int P = c.wp_paths, W = c.wp_len;
   const VehState s = load_vehicle(a, gid, total);
@@ -753,7 +772,15 @@ __device__ __forceinline__ void respawn_vehicle(const KernelArgs& a, size_t gid,
   SF(SMX_S_U) = sp[3];
   SF(SMX_S_PREV_X) = sp[0];
   SF(SMX_S_PREV_Y) = sp[1];
-  a.st.flags[gid] = SMX_F_ALIVE | SMX_F_FIRST;
+  int fl = SMX_F_ALIVE | SMX_F_FIRST;
+  const int n_veh = a.cfg.num_vehicles;
+  if ((int)(gid % n_veh) >= n_veh - a.cfg.num_social) {
+    const double* so = a.sp.social + ((size_t)row * total + gid) * 2;
+    SF(SMX_S_MCL_X) = so[0];  // lane
+    SF(SMX_S_MCL_Y) = so[1];  // arclength offset
+    fl |= SMX_F_SOCIAL;
+  }
+  a.st.flags[gid] = fl;
   a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
 }
 
@@ -862,8 +889,16 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
   __syncthreads();
 
   const bool first = (flags & SMX_F_FIRST) != 0;
-  const bool mine = valid && alive && (!a.first_only || first);
+  const bool social = (flags & SMX_F_SOCIAL) != 0;
+  const bool mine = valid && alive && !social && (!a.first_only || first);
   bool done = false;
+  if (valid && alive && social && first) {
+    // nothing to observe: its rows read as an absent agent's
+    zero_dense_rows(a, gid);
+    o.active[gid] = 0;
+    o.done[gid] = 0;
+    a.st.flags[gid] = flags & ~SMX_F_FIRST;
+  }
   if (mine) {
     const double px = s.x, py = s.y;
     int steps = a.st.steps[gid];
@@ -1089,7 +1124,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
       int dcnt = a.st.env_done_count[env] + env_new_done[env_local];
       a.st.env_done_count[env] = dcnt;
       a.st.env_ticks[env] = a.st.env_ticks[env] + 1;
-      bool all_done = dcnt >= n_veh;  // hiway_env.py:258-261
+      bool all_done = dcnt >= n_veh - c.num_social;  // every agent (hiway_env.py:258-261)
       o.env_done[env] = all_done ? 1 : 0;
       a.st.env_reset_pending[env] = 0;
       env_respawn[env_local] = (all_done && c.auto_reset) ? 1 : 0;
@@ -1130,7 +1165,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) {
   const size_t gid = blockIdx.x;
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
-  const bool live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
+  const bool live = (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
   if (!live) return;  // uniform for the whole workgroup
   const int W = c.ogm_width, H = c.ogm_height;
   const int n_veh = c.num_vehicles;
@@ -1192,7 +1227,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
   const size_t gid = blockIdx.x;
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
-  const bool live = (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST));
+  const bool live = (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
   if (!live) return;
   const int n_veh = c.num_vehicles;
   const int env = (int)(gid / n_veh);
@@ -1439,6 +1474,10 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
+  if (c.num_social < 0 || c.num_social >= c.num_vehicles)
+    return fail(h, SMX_ERR_INVALID, "num_social must leave at least one agent slot");
+  if (c.num_social > 0 && !(c.social_speed_factor >= 0.0))
+    return fail(h, SMX_ERR_INVALID, "social_speed_factor must be >= 0");
   if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED)
     return fail(h, SMX_ERR_INVALID, "unknown action_space");
   if ((c.sensors & SMX_SENSOR_OGM) &&
@@ -1570,6 +1609,7 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
       !st->seed_cache || !st->facts_i32 || !st->facts_f64 || !st->env_reset_pending)
     return fail(h, SMX_ERR_INVALID, "null state buffer");
   if (!sp->pose || sp->episodes < 1) return fail(h, SMX_ERR_INVALID, "spawn table is empty");
+  if (h->cfg.num_social > 0 && !sp->social) return fail(h, SMX_ERR_INVALID, "num_social > 0 needs smx_spawns.social");
   if (!o->ego_pos || !o->ego_f32 || !o->ego_lane || !o->events || !o->reward || !o->dist || !o->done || !o->active ||
       !o->env_done)
     return fail(h, SMX_ERR_INVALID, "null output buffer");

@@ -442,3 +442,49 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
   }
   s.heading = wrap_heading(s.heading);
 }
+
+
+// ---------------------------------------------------------------------------------
+// Scripted social vehicle (include/smx.h smx_config.num_social): one tick of a kinematic lane
+// follower.  `lane` / `offset` locate it on a centre line (smx_shape_rec.cum is the arclength);
+// at a lane's end it continues on outgoing lane (slot + crossed) mod #outgoing, or stops there if
+// the lane has none.  Pose: the point at `offset`, heading of the segment that holds it.
+// ---------------------------------------------------------------------------------
+__device__ inline void social_pose(const MapDev& m, int lane, double offset, double& x, double& y, double& heading) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  int seg = v1 - 2;
+  for (int v = v0; v + 1 < v1; ++v) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.cum + a.len > offset) {
+      seg = v;
+      break;
+    }
+  }
+  if (seg < v0) seg = v0;  // a one-vertex lane cannot exist (the map compiler drops them)
+  const smx_shape_rec a = m.shape_rec[seg], b = m.shape_rec[seg + 1];
+  const double along = fmin(fmax(offset - a.cum, 0.0), a.len);
+  const double f = a.len > 0.0 ? along / a.len : 0.0;
+  x = a.x + (b.x - a.x) * f;
+  y = a.y + (b.y - a.y) * f;
+  heading = wrap_heading(atan2(b.y - a.y, b.x - a.x) - 0.5 * SMX_PI);
+}
+
+__device__ inline void social_step(const MapDev& m, int slot, double factor, double dt, int& lane, double& offset,
+                                   int& crossed, double& speed) {
+  speed = m.lane_speed[lane] * factor;
+  offset += speed * dt;
+  for (int guard = 0; guard < 64; ++guard) {
+    const int v1 = m.lane_shape_off[lane + 1];
+    const double L = m.shape_rec[v1 - 1].cum;
+    if (offset < L) break;
+    const int a = m.lane_out_off[lane], n_out = m.lane_out_off[lane + 1] - a;
+    if (n_out <= 0) {
+      offset = L;
+      speed = 0.0;
+      break;
+    }
+    offset -= L;
+    lane = m.lane_out_idx[a + (slot + crossed) % n_out];
+    ++crossed;
+  }
+}

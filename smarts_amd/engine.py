@@ -51,6 +51,8 @@ class SimConfig:
     ogm_height: int = 256
     ogm_resolution: float = 50 / 256
     lidar: Optional[SensorParams] = None  # agent_interface.py:132-135
+    num_social: int = 0  # scripted social vehicles: the last num_social slots of every env (include/smx.h)
+    social_speed_factor: float = 0.8
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
 
     def sensors_mask(self) -> int:
@@ -93,19 +95,26 @@ def lane_heading(shape: np.ndarray, seg: int) -> float:
 
 
 def make_spawns(cm: CompiledMap, num_envs: int, num_vehicles: int, episodes: int = 1, seed: int = 42,
-                first_env: int = 0, min_gap: float = 8.0) -> np.ndarray:
+                first_env: int = 0, min_gap: float = 8.0, return_lanes: bool = False):
     """Synthetic spawn table: vehicle k of env e starts on lane (k mod L) of the
     map's normal lanes at an arclength drawn U(0.05, 0.95)*lane_length from
     ``numpy.random.Generator(PCG64(seed + e))``, re-drawn while within ``min_gap`` metres of an
     earlier vehicle on that lane; heading = lane heading, speed = lane speed limit.
-    Returns ``[episodes, num_envs * num_vehicles, 4]`` (x, y, heading, speed)."""
+    Returns ``[episodes, num_envs * num_vehicles, 4]`` (x, y, heading, speed); with
+    ``return_lanes`` also ``[episodes, num_envs * num_vehicles, 2]`` (lane index, arclength), which
+    is what scripted social vehicles start from."""
     lanes = [i for i in range(cm.n_lanes) if not cm.lane_in_junction[i]]
     shapes = [cm.lane_shape(i) for i in lanes]
     cums = []
     for sh in shapes:
-        seg = np.sqrt(((sh[1:] - sh[:-1]) ** 2).sum(axis=1))
-        cums.append(np.concatenate(([0.0], np.cumsum(seg))))
+        acc, cum = 0.0, [0.0]
+        for a, b in zip(sh[:-1], sh[1:]):  # vertex by vertex, like smx_shape_rec.cum
+            ex, ey = float(a[0] - b[0]), float(a[1] - b[1])
+            acc = acc + math.sqrt(ex * ex + ey * ey)
+            cum.append(acc)
+        cums.append(np.array(cum))
     out = np.zeros((episodes, num_envs * num_vehicles, 4), dtype=np.float64)
+    where = np.zeros((episodes, num_envs * num_vehicles, 2), dtype=np.float64)
     L = len(lanes)
     for e in range(num_envs):
         rng = np.random.Generator(np.random.PCG64(seed + first_env + e))
@@ -127,7 +136,8 @@ def make_spawns(cm: CompiledMap, num_envs: int, num_vehicles: int, episodes: int
                 x = sh[seg, 0] + (sh[seg + 1, 0] - sh[seg, 0]) * f
                 y = sh[seg, 1] + (sh[seg + 1, 1] - sh[seg, 1]) * f
                 out[ep, e * num_vehicles + k] = (x, y, lane_heading(sh, seg), cm.lane_speed[lanes[li]])
-    return out
+                where[ep, e * num_vehicles + k] = (lanes[li], off)
+    return (out, where) if return_lanes else out
 
 
 _MAP_ARRAYS = [
@@ -172,7 +182,7 @@ class BatchedSim:
     """One shard of environment instances resident on one GPU."""
 
     def __init__(self, cm: CompiledMap, cfg: SimConfig, device: str = "cuda:0", spawns: Optional[np.ndarray] = None,
-                 spawn_episodes: int = 2, seed: int = 42, first_env: int = 0):
+                 spawn_episodes: int = 2, seed: int = 42, first_env: int = 0, social_spawns: Optional[np.ndarray] = None):
         self.lib = nat.load_library()
         if not torch.cuda.is_available():
             raise nat.NativeLibraryError("no ROCm device visible: the smarts_amd hot path runs on the GPU only")
@@ -198,6 +208,7 @@ class BatchedSim:
             raise ValueError(f"action space {cfg.action_space!r} is not on the accelerated path "
                              f"(supported: {sorted(nat.ACTION_SPACES)})")
         c.action_space = nat.ACTION_SPACES[cfg.action_space]
+        c.num_social, c.social_speed_factor = int(cfg.num_social), float(cfg.social_speed_factor)
         if cfg.ogm:
             c.ogm_width, c.ogm_height, c.ogm_resolution = cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution
         if cfg.lidar is not None:
@@ -240,12 +251,24 @@ class BatchedSim:
 
         # ---- spawns ----
         if spawns is None:
-            spawns = make_spawns(cm, E, N, episodes=spawn_episodes, seed=seed, first_env=first_env)
+            spawns, where = make_spawns(cm, E, N, episodes=spawn_episodes, seed=seed, first_env=first_env,
+                                        return_lanes=True)
+            if social_spawns is None:
+                social_spawns = where
         spawns = np.ascontiguousarray(spawns, dtype=np.float64)
         assert spawns.ndim == 3 and spawns.shape[1:] == (T, 4), spawns.shape
         self.spawns = torch.from_numpy(spawns).to(dev)
         sp = nat.SmxSpawns()
         sp.episodes, sp.pose = int(spawns.shape[0]), self.spawns.data_ptr()
+        self.social_spawns = None
+        if cfg.num_social > 0:
+            if social_spawns is None:
+                raise ValueError("num_social > 0 with an explicit spawn table needs social_spawns "
+                                 "(make_spawns(..., return_lanes=True))")
+            social_spawns = np.ascontiguousarray(social_spawns, dtype=np.float64)
+            assert social_spawns.shape == (spawns.shape[0], T, 2), social_spawns.shape
+            self.social_spawns = torch.from_numpy(social_spawns).to(dev)
+            sp.social = self.social_spawns.data_ptr()
         self._sp = sp
 
         # ---- outputs (dense StdObs layout, format_obs.py:313-373) ----

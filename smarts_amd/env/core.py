@@ -72,7 +72,7 @@ def encode_float_action(space: ActionSpaceType, action: Any):
 
 
 def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: int, dt: float, auto_reset: bool,
-                              waypoint_window: Tuple[int, int] = (4, 20)):
+                              waypoint_window: Tuple[int, int] = (4, 20), num_social: int = 0):
     """AgentInterface -> SimConfig (one interface for every agent, as FormatObs also requires,
     format_obs.py:207-210)."""
     from ..engine import SimConfig
@@ -80,7 +80,7 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
     itf.validate_for_device()
     dc, evc = itf.done_criteria, itf.event_configuration
     kw: Dict[str, Any] = dict(
-        num_envs=num_envs, num_vehicles=num_agents, dt=dt,
+        num_envs=num_envs, num_vehicles=num_agents + num_social, num_social=num_social, dt=dt,
         waypoints=bool(itf.waypoints), wp_lookahead=itf.waypoints.lookahead if itf.waypoints else 32,
         neighbors=bool(itf.neighborhood_vehicles),
         nb_radius=itf.neighborhood_vehicles.radius if itf.neighborhood_vehicles else None,
@@ -105,7 +105,8 @@ class BatchCore:
     """E env instances of one scenario x the agents of ``agent_specs`` on one device."""
 
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
-                 auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20)):
+                 auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20),
+                 num_social: int = 0):
         from ..engine import BatchedSim, make_spawns
         from ..map_compiler import compile_map
         from ..sumo_map import load_net
@@ -123,12 +124,14 @@ class BatchCore:
         self.scenario_dir = resolve_scenario(scenario_dir)
         self.net = load_net(self.scenario_dir)
         self.cm = compile_map(self.net)
-        self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window)
-        spawns = make_spawns(self.cm, num_envs, self.N, episodes=4, seed=seed)
-        self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed)
+        self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window, num_social)
+        self.num_social = num_social
+        spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)
+        self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed, social_spawns=where)
         road_ids = [self.cm.road_ids[r] for r in self.cm.lane_road]
+        vehicle_names = self.agent_ids + [f"social-{k}" for k in range(num_social)]
         self.builder = ObservationBuilder(
-            self.cm.lane_ids, road_ids, self.agent_ids, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
+            self.cm.lane_ids, road_ids, vehicle_names, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
             accelerometer=self.cfg.accelerometer, ogm=first.ogm or None,
             lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt)
         self._was_reset = False
@@ -157,10 +160,11 @@ class BatchCore:
     def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
         space = self.interface.action
         lane = space is ActionSpaceType.Lane
+        slots = self.N + self.num_social
         if lane:
-            acts = np.full((self.E, self.N), NO_ACTION, dtype=np.int8)
+            acts = np.full((self.E, slots), NO_ACTION, dtype=np.int8)
         else:
-            acts = np.full((self.E, self.N, 3), np.nan, dtype=np.float32)  # NaN = no action
+            acts = np.full((self.E, slots, 3), np.nan, dtype=np.float32)  # NaN = no action
         for e, agent_actions in enumerate(per_env_actions):
             assert isinstance(agent_actions, dict) and all(isinstance(k, str) for k in agent_actions), \
                 "Expected Dict[str, any]"  # hiway_env.py:232-234

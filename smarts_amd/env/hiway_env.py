@@ -43,6 +43,7 @@ class HiWayEnv:
         timestep_sec: Optional[float] = None,  # deprecated alias (hiway_env.py:107-113)
         device: str = "cuda:0",
         waypoint_window: Tuple[int, int] = (4, 20),
+        num_social: int = 0,
     ):
         self._log = logging.getLogger(self.__class__.__name__)
         if not headless or envision_record_data_replay_path or envision_endpoint:
@@ -63,6 +64,8 @@ class HiWayEnv:
         self._dt = float(fixed_timestep_sec)
         self._device = device
         self._waypoint_window = waypoint_window
+        # scripted social traffic (the accelerated path's stand-in for the scenario's SUMO flows)
+        self._num_social = int(num_social)
         self._dones_registered = 0
         self._core: Optional[BatchCore] = None
         self._seed = seed
@@ -93,7 +96,7 @@ class HiWayEnv:
         """What must agree for envs to share one device batch (ParallelEnv)."""
         specs = self._agent_specs
         return (self._scenario, tuple(specs.keys()), tuple(repr(s.interface) for s in specs.values()), self._dt,
-                self._waypoint_window)
+                self._waypoint_window, self._num_social)
 
     def seed(self, seed: int) -> int:
         """hiway_env.py:204-214.  Takes effect at the next ``reset`` that (re)builds the spawn table."""
@@ -111,7 +114,8 @@ class HiWayEnv:
             raise SMARTSDestroyedError("BUG: SMARTS was destroyed and is no longer usable")
         if self._core is None:
             self._core = BatchCore(self._scenario, self._agent_specs, num_envs=1, dt=self._dt, seed=self._seed,
-                                   auto_reset=False, device=self._device, waypoint_window=self._waypoint_window)
+                                   auto_reset=False, device=self._device, waypoint_window=self._waypoint_window,
+                                   num_social=self._num_social)
         return self._core
 
     def step(self, agent_actions) -> Tuple[Dict[str, Observation], Dict[str, float], Dict[str, bool], Dict[str, Any]]:

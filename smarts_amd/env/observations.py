@@ -210,8 +210,10 @@ class ObservationBuilder:
         self.ogm, self.lidar_rays, self.dt = ogm, lidar_rays, dt
 
     def vehicle_id(self, slot: int) -> str:
-        # Vehicle.build_agent_vehicle (vehicle.py:371-372) names agent vehicles after their agent
-        return f"{self.agent_ids[slot]}-vehicle"
+        # Vehicle.build_agent_vehicle (vehicle.py:371-372) names agent vehicles after their agent;
+        # scripted social vehicles (slots after the agents) keep their own name
+        name = self.agent_ids[slot]
+        return name if name.startswith("social-") else f"{name}-vehicle"
 
     def _lane(self, lane: int, lane_index: int):
         if lane < 0:

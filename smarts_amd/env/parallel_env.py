@@ -58,7 +58,8 @@ class ParallelEnv:
             self._core.close()
         p = self._proto
         self._core = BatchCore(p._scenario, p.agent_specs, num_envs=self._num_envs, dt=p._dt, seed=seed,
-                               auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window)
+                               auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window,
+                               num_social=p._num_social)
         self._seed = seed
         return [seed + i for i in range(self._num_envs)]
 

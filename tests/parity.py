@@ -162,16 +162,21 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
 class OracleBatch:
     """E independent oracle envs driven with the same spawns/actions as the device."""
 
-    def __init__(self, net, cm, cfg, spawns_ep0):
+    def __init__(self, net, cm, cfg, spawns_ep0, social_ep0=None):
         self.cfg = cfg
         self.road_map = ORoadNetwork(net, lanepoint_spacing=cm.lanepoint_spacing)
         self.lane_no = {lid: i for i, lid in enumerate(cm.lane_ids)}
         self.N = cfg.num_vehicles
         ocfg = oracle_config(cfg)
-        self.envs = [
-            OracleEnv(self.road_map, spawns_ep0[e * self.N:(e + 1) * self.N], [ocfg] * self.N, dt=cfg.dt)
-            for e in range(cfg.num_envs)
-        ]
+        K = cfg.num_social
+        self.envs = []
+        for e in range(cfg.num_envs):
+            rows = slice(e * self.N, (e + 1) * self.N)
+            social = []
+            if K:
+                social = [(cm.lane_ids[int(l)], float(off)) for l, off in social_ep0[rows][self.N - K:]]
+            self.envs.append(OracleEnv(self.road_map, spawns_ep0[rows], [ocfg] * (self.N - K), dt=cfg.dt, social=social,
+                                       social_speed_factor=cfg.social_speed_factor))
 
     def _stack(self, parts):
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
@@ -222,3 +227,9 @@ def sync_oracle_from_device(ob: "OracleBatch", sim):
             if len(ag.linear_velocities) >= 2:
                 ag.linear_velocities[-2] = np.array([st[S["LV1_LONG"], g], st[S["LV1_LAT"], g], 0.0])
                 ag.angular_velocities[-2] = np.array([0.0, 0.0, st[S["AV1_Z"], g]])
+        for k, sv in enumerate(env.social):
+            g = e * ob.N + len(env.agents) + k
+            b = sv.body
+            b.x, b.y, b.heading, b.u = st[S["X"], g], st[S["Y"], g], st[S["HEADING"], g], st[S["U"], g]
+            b.lane = ob.road_map.lane_by_id(lane_ids[int(st[S["MCL_X"], g])])
+            b.offset, b.crossed = float(st[S["MCL_Y"], g]), int(st[S["SPD_INT"], g])

@@ -177,3 +177,19 @@ def test_parallel_env_dense_path_stays_on_device():
     s = FormatObs.from_rows(rows, 3, 1)
     assert s.waypoints["pos"].shape == (4, 20, 3) and s.ego["pos"].dtype == np.float64 and s.dist.dtype == np.float32
     env.close()
+
+
+def test_hiway_env_with_scripted_social_traffic():
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Laner, neighborhood_vehicles=True, max_episode_steps=30),
+                     agent_builder=lambda: Agent.from_function(lambda _: "keep_lane"))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={"A": spec, "B": spec}, seed=3, num_social=12)
+    obs = env.reset()
+    assert set(obs) == {"A", "B"}
+    ids = {v.id for v in obs["A"].neighborhood_vehicle_states}
+    assert "B-vehicle" in ids and any(i.startswith("social-") for i in ids) and len(ids) == 10  # the dense rows keep the first ten (format_obs.py:41)
+    for _ in range(5):
+        obs, rewards, dones, infos = env.step({"A": "keep_lane", "B": "slow_down"})
+    assert set(rewards) == {"A", "B"} and not dones["__all__"]
+    env.close()

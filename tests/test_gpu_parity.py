@@ -163,6 +163,46 @@ def test_config_variants(variant, name, E, N, nets, compiled_maps):
     sim.close()
 
 
+@pytest.mark.parametrize("name,E,agents,social,T,seed", [("loop", 3, 6, 10, 60, 51), ("4lane", 2, 4, 12, 40, 52),
+                                                         ("minicity", 1, 8, 40, 25, 53)])
+def test_scripted_social_traffic(name, E, agents, social, T, seed, nets, compiled_maps):
+    """include/smx.h smx_config.num_social: kinematic lane followers in the last slots of every env —
+    visible to the agents' neighbourhood / collision / OGM sensors, silent themselves."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps(name)
+    N = agents + social
+    cfg = SimConfig(num_envs=E, num_vehicles=N, num_social=social, neighbors=True, nb_radius=60.0, done_collision=True,
+                    ogm=(name == "loop"), ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
+    spawns, where = make_spawns(cm, E, N, episodes=2, seed=seed, return_lanes=True)
+    sim = BatchedSim(cm, cfg, spawns=spawns, social_spawns=where)
+    ob = parity.OracleBatch(nets(name), cm, cfg, spawns[0], where[0])
+    # the two lane graphs must list successors in the same order for the social model to agree
+    for lane_idx in range(cm.n_lanes):
+        outs = [cm.lane_ids[j] for j in cm.lane_out_idx[cm.lane_out_off[lane_idx]:cm.lane_out_off[lane_idx + 1]]]
+        assert outs == [l.lane_id for l in ob.road_map.lane_by_id(cm.lane_ids[lane_idx]).outgoing_lanes]
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    assert d["active"].reshape(E, N)[:, agents:].sum() == 0  # social slots never observe
+    rng = np.random.default_rng(seed)
+    saw_social_neighbour = collided = 0
+    pos0 = sim.state[0:2, :, agents:].clone()
+    for t in range(T):
+        acts = _actions(rng, E, N)
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{name} t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        saw_social_neighbour += int((d["nb_slot"] >= agents).sum())
+        collided += int(d["events"][:, 0].sum())
+        parity.sync_oracle_from_device(ob, sim)
+    assert saw_social_neighbour > 0
+    moved = (sim.state[0:2, :, agents:] - pos0).norm(dim=0)
+    assert float(moved.median()) > 5.0  # the social fleet drove on (dead-end lanes stop their vehicles)
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 
