@@ -162,8 +162,9 @@ def main():
     out = sim.reset()
 
     def tick(i):
+        gather.release(sim.next_learner_block)  # the gather of two ticks ago has read it
         o = sim.step(actions[i % ACTION_CYCLE])
-        gather.start(o["reward"], o["done"])  # learner-side block; overlaps the next tick
+        gather.start_packed(o["learner"])  # learner-side {reward, done} block; overlaps the next tick
 
     for i in range(args.warmup):
         tick(i)

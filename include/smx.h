@@ -271,6 +271,10 @@ typedef struct smx_outputs {
   uint8_t* done;         /* [E*N]                                             */
   uint8_t* active;       /* [E*N] 1 while the agent has a vehicle after this tick */
   uint8_t* env_done;     /* [E]   dones["__all__"] (hiway_env.py:258-261)     */
+  /* optional learner-facing block [2][E*N] float32: row 0 = reward, row 1 = done, rewritten whole
+   * every tick (absent agents read 0) — what a multi-GPU job gathers per tick;
+   * the caller may alternate buffers between ticks.  NULL if unused. */
+  float* learner;
   /* waypoints sensor, [E*N][wp_paths][wp_len] */
   double* wp_pos;        /* ...[3], z = 0 (format_obs.py:594)                 */
   float* wp_heading;

@@ -80,7 +80,7 @@ class SmxSpawns(C.Structure):
 
 
 OUTPUT_FIELDS = [
-    "ego_pos", "ego_f32", "ego_lane", "events", "reward", "dist", "done", "active", "env_done",
+    "ego_pos", "ego_f32", "ego_lane", "events", "reward", "dist", "done", "active", "env_done", "learner",
     "wp_pos", "wp_heading", "wp_lane_width", "wp_speed_limit", "wp_lane_index", "wp_lane_id", "wp_count",
     "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
     "ogm", "lidar_hit", "lidar_point",

@@ -751,7 +751,10 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
   }
   SF(SMX_S_DIST) = dist;
   o.dist[gid] = dist;
-  if (!a.keep_reward_done) o.reward[gid] = dist - last_dist;
+  if (!a.keep_reward_done) {
+    o.reward[gid] = dist - last_dist;
+    if (o.learner) o.learner[gid] = (float)(dist - last_dist);
+  }
   // only the trip-meter bit may change here; k_observe owns the other flag bits
   a.st.flags[gid] = (a.st.flags[gid] & ~SMX_F_TRIP_HAS_WP) | (flags & SMX_F_TRIP_HAS_WP);
 }
@@ -1107,10 +1110,17 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
     // the trip-meter bit belongs to k_waypoints (same launch sequence, earlier kernel)
     a.st.flags[gid] = (flags & ~SMX_F_TRIP_HAS_WP) | (a.st.flags[gid] & SMX_F_TRIP_HAS_WP);
     o.active[gid] = done ? 0 : 1;
-    if (!a.keep_reward_done) o.done[gid] = done ? 1 : 0;
-  } else if (valid && !alive && !a.first_only) {
+    if (!a.keep_reward_done) {
+      o.done[gid] = done ? 1 : 0;
+      if (o.learner) o.learner[total + gid] = done ? 1.0f : 0.0f;
+    }
+  } else if (valid && !a.first_only) {
+    if (o.learner && (!alive || social)) {
+      o.learner[gid] = 0.0f;  // no agent in this slot: absent from the learner block
+      o.learner[total + gid] = 0.0f;
+    }
     // an agent whose vehicle is gone: absent from the observations (zeros), done stays 0
-    if (o.active[gid] != 0 || o.done[gid] != 0) {
+    if (!alive && (o.active[gid] != 0 || o.done[gid] != 0)) {
       zero_dense_rows(a, gid);
       o.done[gid] = 0;
       o.active[gid] = 0;

@@ -308,6 +308,11 @@ class BatchedSim:
             R = ray_count(cfg.lidar)
             o["lidar_hit"] = z((E, N, R), torch.uint8)
             o["lidar_point"] = z((E, N, R, 3), torch.float64)
+        # learner-facing block (reward, done) as float32, two buffers used on alternate ticks so that
+        # one can be in flight in a collective while the next tick writes the other
+        self._learner = [z((2, E, N), torch.float32), z((2, E, N), torch.float32)]
+        self._learner_k = 0
+        o["learner"] = self._learner[0]
         self.out = o
         so = nat.SmxOutputs()
         for name in nat.OUTPUT_FIELDS:
@@ -324,7 +329,7 @@ class BatchedSim:
         """Bytes of observation/reward/done written per agent-step (dense layout)."""
         per = 0
         for name, t in self.out.items():
-            if name in ("env_done",):
+            if name in ("env_done", "learner"):
                 continue
             per += t[0, 0].numel() * t.element_size()
         return per
@@ -336,7 +341,8 @@ class BatchedSim:
         """Algorithmic HBM bytes of one agent-step, attributed to the kernel that must move them
         (DESIGN.md "Kernels"): compulsory reads of per-vehicle state/action plus every output byte,
         map tables (L2/LDS resident) not counted — SURVEY.md §8(d)'s accounting on this layout."""
-        o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items() if k != "env_done"}
+        o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items() if k not in ("env_done", "learner")}
+        o["learner_block"] = 8  # reward + done as float32
         seeds, facts = nat.SEED_COUNT * 4, nat.FACT_I_COUNT * 4 + nat.FACT_F_COUNT * 8
         state = nat.S_COUNT * 8 + 4 + 4
         kb = {
@@ -371,6 +377,9 @@ class BatchedSim:
     def step(self, actions: torch.Tensor) -> Dict[str, torch.Tensor]:
         if not self._was_reset:
             raise RuntimeError("step() before reset()")  # SMARTSNotSetupError (smarts.py:207-208)
+        self._learner_k ^= 1
+        self.out["learner"] = self._learner[self._learner_k]
+        self._out.learner = self.out["learner"].data_ptr()
         if self.cfg.action_space == "Lane":
             if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
                 actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
@@ -387,6 +396,11 @@ class BatchedSim:
                                               C.byref(self._out), self._stream_ptr())
             nat.check(self.lib, self.handle, rc, "smx_step_continuous")
         return self.out
+
+    @property
+    def next_learner_block(self) -> torch.Tensor:
+        """The learner block the NEXT ``step`` will write (see ``RewardDoneGather.release``)."""
+        return self._learner[self._learner_k ^ 1]
 
     def set_timing(self, level):
         """0/False = off, 1/True = one event pair per smx_step, 2 = per-kernel phases."""

@@ -71,12 +71,20 @@ class RewardDoneGather:
         self.send = [torch.zeros((2, self.n), dtype=torch.float32, device=device) for _ in range(2)]
         self.recv = [torch.zeros((world_size, 2, self.n), dtype=torch.float32, device=device) for _ in range(2)]
         self.work = [None, None]
+        self.src = [None, None]  # data_ptr of the caller's block a pending gather reads from
         self.k = 0  # pair used by the latest start()
 
     def _wait(self, k: int):
         if self.work[k] is not None:
             self.work[k].wait()  # NCCL: makes the current stream wait; gloo: blocks the host
             self.work[k] = None
+        self.src[k] = None
+
+    def release(self, block: torch.Tensor) -> None:
+        """Call before enqueuing work that overwrites ``block``: waits for a gather still reading it."""
+        for k in (0, 1):
+            if self.src[k] is not None and self.src[k] == block.data_ptr():
+                self._wait(k)
 
     def start(self, reward: torch.Tensor, done: torch.Tensor) -> None:
         k = self.k ^ 1
@@ -87,6 +95,20 @@ class RewardDoneGather:
             self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), self.send[k].view(-1), async_op=True)
         else:
             self.recv[k][0].copy_(self.send[k])
+        self.k = k
+
+    def start_packed(self, block: torch.Tensor) -> None:
+        """The same for a block the kernels already packed (``BatchedSim.out["learner"]``,
+        float32 ``[2, E, N]``): no packing kernels; the block must stay untouched until the gather
+        launched from it has been waited for (BatchedSim alternates two of them)."""
+        k = self.k ^ 1
+        self._wait(k)
+        flat = block.reshape(-1)
+        if self.world > 1:
+            self.work[k] = dist.all_gather_into_tensor(self.recv[k].view(-1), flat, async_op=True)
+            self.src[k] = block.data_ptr()
+        else:
+            self.recv[k] = block.reshape(1, 2, self.n)  # single process: the block itself
         self.k = k
 
     def result(self) -> torch.Tensor:

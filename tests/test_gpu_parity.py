@@ -253,6 +253,33 @@ def test_done_agents_leave_and_auto_reset(nets, compiled_maps):
     sim.close()
 
 
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_learner_block_is_reward_and_done(auto_reset, compiled_maps):
+    """smx_outputs.learner: float32 [2][E*N] = (reward, done) rewritten whole every tick on
+    alternating buffers, zeros for agents that have left."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig
+
+    cm = compiled_maps("loop")
+    E, N = 4, 8
+    sim = BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, max_episode_steps=5, auto_reset=auto_reset, num_social=2))
+    sim.reset()
+    acts = torch.zeros((E, N), dtype=torch.int8, device="cuda")
+    seen = set()
+    for t in range(12):
+        out = sim.step(acts)
+        torch.cuda.synchronize()
+        block = out["learner"]
+        seen.add(block.data_ptr())
+        assert torch.equal(block[0], out["reward"].float()), t
+        assert torch.equal(block[1], out["done"].float()), t
+        assert float(block[:, :, N - 2:].abs().sum()) == 0.0  # social slots
+        assert sim.next_learner_block.data_ptr() != block.data_ptr()
+    assert len(seen) == 2
+    sim.close()
+
+
 def test_full_size_properties(compiled_maps):
     """BASELINE config sizes through size-independent properties: env independence (a shard of
     the batch computes the same thing as the whole batch), determinism, and invariants of the
@@ -282,7 +309,8 @@ def test_full_size_properties(compiled_maps):
     for k in o1:
         a, b, c = o1[k].cpu().numpy(), o2[k].cpu().numpy(), o3[k].cpu().numpy()
         assert np.array_equal(a, c, equal_nan=True), f"{k}: two identical runs differ"
-        assert np.array_equal(a[E - sub:], b, equal_nan=True), f"{k}: env results depend on batch placement"
+        part = a[:, E - sub:] if k == "learner" else a[E - sub:]  # the learner block is [2, E, N]
+        assert np.array_equal(part, b, equal_nan=True), f"{k}: env results depend on batch placement"
     act = o1["active"].cpu().numpy().astype(bool)
     wpc = o1["wp_count"].cpu().numpy()
     assert (wpc[act][:, 0] >= 1).all() and (wpc[act][:, 1] == cfg.wp_len).all()

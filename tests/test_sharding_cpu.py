@@ -53,6 +53,17 @@ def _worker(rank, world, port, q):
         seen.append(g.result()[:, 0, 0].clone())
     g.finish()
     assert all(float(seen[t][src]) == t + 100 * src for t in range(3) for src in range(world))
+    # packed form: the caller's own alternating blocks are gathered without a packing copy
+    blocks = [torch.zeros((2, E, N), dtype=torch.float32), torch.zeros((2, E, N), dtype=torch.float32)]
+    for t in range(4):
+        b = blocks[t % 2]
+        g.release(b)
+        b[0].fill_(10 * t + rank)
+        b[1].fill_(rank)
+        g.start_packed(b)
+        got = g.result()
+        assert all(float(got[src, 0, 0]) == 10 * t + src and float(got[src, 1, -1]) == src for src in range(world))
+    g.finish()
     q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
