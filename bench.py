@@ -6,8 +6,8 @@
 
 A "step" is one SMARTS tick of every environment instance of the shard: controllers, vehicle
 dynamics, collisions, sensors/observation build, events/reward/done and auto-reset — one
-``smx_step`` call, which enqueues the tick's kernels (k_control, k_scan, [k_ogm], [k_lidar],
-k_waypoints, k_observe and, with auto-reset, the reset pass) on one stream.
+``smx_step`` call, which enqueues the tick's kernels (k_control, k_scan, [k_ogm], k_sensors, k_commit
+and, with auto-reset, the reset pass) on one stream.
 Workload at every N: BASELINE configs[1] per GPU — scenarios/loop, 1024 batched envs x 8 Laner
 agents, waypoints (4, 20) + neighbourhood (10, 50 m) observations, dt = 0.1 s, synthetic
 spawns / action stream per SURVEY.md §8d (weak scaling: each rank owns its own 1024 envs; no
@@ -219,15 +219,14 @@ def main():
             kernels = {}
             for name, ms in zip(PHASES, phase_ms):
                 ms = float(ms)
-                if name in ("ogm", "lidar") and name not in kb:
+                if name == "ogm" and name not in kb:
                     continue
                 b = kb.get(name, 0) * E * N
                 kernels["k_" + name if name != "reset" else "reset_pass"] = {
                     "avg_ms": ms, "algorithmic_bytes": b,
                     "GB/s": (b / (ms * 1e-3) / 1e9) if ms > 0 and b else None,
                 }
-            obs_build_ms = float(sum(ms for n_, ms in zip(PHASES, phase_ms) if n_ in ("scan", "ogm", "lidar", "waypoints",
-                                                                                     "observe")))
+            obs_build_ms = float(sum(ms for n_, ms in zip(PHASES, phase_ms) if n_ in ("scan", "ogm", "sensors", "commit")))
             dominant = max((k for k in kernels if k != "reset_pass"), key=lambda k: kernels[k]["avg_ms"])
         line = {
             "metric": "aggregate env-steps/s (all agents)",
@@ -262,8 +261,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
-                "kernel": "smx_step: k_control > k_scan > [k_ogm] > [k_lidar] > k_waypoints > k_observe > reset pass "
-                          "(one launch sequence per tick; duration = HIP events around the sequence on its stream)",
+                "kernel": "smx_step: k_control > k_scan > [k_ogm] > k_sensors (waypoints | observe | [lidar] roles) > "
+                          "k_commit > reset pass (one launch sequence per tick; duration = HIP events around the "
+                          "sequence on its stream)",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "bytes_per_agent_step": bytes_agent,
                 "dominant_kernel": dominant,

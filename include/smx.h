@@ -208,7 +208,7 @@ enum {
 enum {
   SMX_F_ALIVE = 1 << 0,
   SMX_F_MCL_SET = 1 << 1,
-  SMX_F_TRIP_HAS_WP = 1 << 2,
+  SMX_F_RESERVED2 = 1 << 2, /* (was the trip-meter bit; now facts_i32[SMX_FI_TRIP_HAS_WP]) */
   SMX_F_HIST_SHIFT = 3, /* bits 3-4: accelerometer samples held (0..2) */
   SMX_F_FIRST = 1 << 5, /* vehicle was just (re)created: its next observation is a reset observation */
   SMX_F_SOCIAL = 1 << 6 /* scripted social vehicle (no controller, no observation) */
@@ -235,7 +235,12 @@ typedef struct smx_state {
   int32_t* env_reset_pending; /* [E] set by the observe kernel when auto_reset fires        */
 } smx_state;
 #define SMX_SEED_COUNT 9 /* road, filter n, filter roads x2, lane count, start lanepoint x4 */
-enum { SMX_FI_LANE = 0, SMX_FI_FLAGS, SMX_FI_TRIP_START, SMX_FI_OBS_START, SMX_FACT_I_COUNT };
+enum {
+  SMX_FI_LANE = 0, SMX_FI_FLAGS, SMX_FI_TRIP_START, SMX_FI_OBS_START,
+  SMX_FI_TRIP_HAS_WP, /* trip meter holds a waypoint (TripMeterSensor._wps_for_distance non-empty); persists across ticks */
+  SMX_FI_FLAGS_NEXT,  /* the flags word after this tick's observation, applied by the commit kernel */
+  SMX_FACT_I_COUNT
+};
 enum { SMX_FF_LANE_DIST = 0, SMX_FF_LANE_HEADING /* lane heading at the nearest centre-line point */, SMX_FACT_F_COUNT };
 enum { SMX_FACT_ON_ROAD = 1 << 0, SMX_FACT_CORNER_SHIFT = 1 /* bits 1-4: corner q on road */ };
 
@@ -324,13 +329,12 @@ int smx_sync(smx_handle h, void* hip_stream);
  * this); 2 = a boundary event after every kernel of the tick, read back per phase with
  * smx_read_phase_ms as ms[n][SMX_PHASE_COUNT] (a phase whose sensor is disabled reads ~0). */
 enum {
-  SMX_PHASE_CONTROL = 0, /* controllers + vehicle dynamics (a1-a6)                 */
-  SMX_PHASE_SCAN,        /* road facts + lanepoint seeds (a8, a9 front half)        */
-  SMX_PHASE_OGM,         /* a14 */
-  SMX_PHASE_LIDAR,       /* a15 */
-  SMX_PHASE_WAYPOINTS,   /* a9 */
-  SMX_PHASE_OBSERVE,     /* a7, a10-a13 */
-  SMX_PHASE_RESET,       /* auto-reset pass (parallel_env.py:303-309), all kernels  */
+  SMX_PHASE_CONTROL = 0, /* k_control: controllers + vehicle dynamics (a1-a6)            */
+  SMX_PHASE_SCAN,        /* k_scan: road facts + lanepoint seeds (a8, a9 front half)      */
+  SMX_PHASE_OGM,         /* k_ogm (a14)                                                   */
+  SMX_PHASE_SENSORS,     /* k_sensors: waypoints | observe | lidar roles (a7, a9-a13, a15) */
+  SMX_PHASE_COMMIT,      /* k_commit: flags, env done count, auto-reset respawn           */
+  SMX_PHASE_RESET,       /* auto-reset pass (parallel_env.py:303-309), all kernels        */
   SMX_PHASE_COUNT
 };
 int smx_set_timing(smx_handle h, int level);

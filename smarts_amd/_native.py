@@ -23,7 +23,7 @@ EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way"
                "reached_max_episode_steps", "agents_alive_done"]
 EV = {name.upper(): i for i, name in enumerate(EVENT_NAMES)}
 ACTION_SPACES = {"Lane": 0, "Continuous": 1, "ActuatorDynamic": 2, "LaneWithContinuousSpeed": 3}
-PHASES = ["control", "scan", "ogm", "lidar", "waypoints", "observe", "reset"]
+PHASES = ["control", "scan", "ogm", "sensors", "commit", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
                 "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
@@ -31,7 +31,7 @@ STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT
 S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
 F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST, F_SOCIAL = 1, 2, 4, 3, 32, 64
-FACT_I_COUNT, FACT_F_COUNT = 4, 2
+FACT_I_COUNT, FACT_F_COUNT = 6, 2
 DRIVEN_PATH_LEN = 500
 SEED_COUNT = 9
 EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,

@@ -50,6 +50,7 @@ struct KernelArgs {
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
   int debug_skip;
+  int wp_blocks, obs_blocks;  // k_sensors: workgroups of the waypoints / observe roles (lidar takes the rest)
   int scan_split;  // k_scan: 1 = the two halves run as separate workgroups (small batches), 0 = one after the other
 };
 
@@ -585,7 +586,7 @@ __device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
   }
 }
 
-__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
+__device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int block) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
   int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
   const smx_outputs& o = a.out;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
-  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
+  const size_t gid = ((size_t)block * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
@@ -716,9 +717,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
   if (p0 != 0) return;
   // ---- trip meter (sensors.py:880-947); reward = increment (agent_manager.py:233-234)
   double dist = SF(SMX_S_DIST);
+  int32_t* trip_has_wp_p = a.st.facts_i32 + (size_t)SMX_FI_TRIP_HAS_WP * total + gid;
+  bool trip_has_wp = *trip_has_wp_p != 0;
   if (flags & SMX_F_FIRST) {
     // TripMeterSensor.__init__: first waypoint of the lowest lane, lookahead-1 path, no route
-    flags &= ~SMX_F_TRIP_HAS_WP;
+    trip_has_wp = false;
     const int ts = a.st.facts_i32[(size_t)SMX_FI_TRIP_START * total + gid];
     if (ts >= 0) {
       BranchState bs;
@@ -729,18 +732,18 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
         SF(SMX_S_TRIP_X) = w.x;
         SF(SMX_S_TRIP_Y) = w.y;
         SF(SMX_S_TRIP_H) = w.heading;
-        flags |= SMX_F_TRIP_HAS_WP;
+        trip_has_wp = true;
       });
     }
     dist = 0.0;
   }
   const double last_dist = dist;
   if (have_first_wp) {
-    if (!(flags & SMX_F_TRIP_HAS_WP)) {
+    if (!trip_has_wp) {
       SF(SMX_S_TRIP_X) = fwx;
       SF(SMX_S_TRIP_Y) = fwy;
       SF(SMX_S_TRIP_H) = fwh;
-      flags |= SMX_F_TRIP_HAS_WP;
+      trip_has_wp = true;
     } else {
       double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
       double dx = fwx - tx, dy = fwy - ty;
@@ -763,8 +766,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) {
     o.reward[gid] = dist - last_dist;
     if (o.learner) o.learner[gid] = (float)(dist - last_dist);
   }
-  // only the trip-meter bit may change here; k_observe owns the other flag bits
-  a.st.flags[gid] = (a.st.flags[gid] & ~SMX_F_TRIP_HAS_WP) | (flags & SMX_F_TRIP_HAS_WP);
+  *trip_has_wp_p = trip_has_wp ? 1 : 0;  // the flags word itself is not written here (the observe role owns it)
 }
 
 // =================================================================================
@@ -792,6 +794,7 @@ __device__ __forceinline__ void respawn_vehicle(const KernelArgs& a, size_t gid,
     fl |= SMX_F_SOCIAL;
   }
   a.st.flags[gid] = fl;
+  a.st.facts_i32[(size_t)SMX_FI_TRIP_HAS_WP * total + gid] = 0;
   a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
 }
 
@@ -852,9 +855,8 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
   }
 }
 
-__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
+__device__ __forceinline__ void observe_role(const KernelArgs& a, const int block) {
   __shared__ SharedPose pose[SMX_BLOCK];
-  __shared__ int env_new_done[SMX_BLOCK];
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
@@ -863,13 +865,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
   const int local = threadIdx.x;
   const int env_local = local / n_veh;
   const int slot = local - env_local * n_veh;
-  const int env = blockIdx.x * epb + env_local;
+  const int env = block * epb + env_local;
   const bool valid = (env_local < epb) && (env < c.num_envs);
   const size_t total = (size_t)c.num_envs * n_veh;
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
   const SharedPose* env_pose = pose + env_local * n_veh;
 
-  env_new_done[local] = 0;
   VehState s = {0, 0, 0, 0, 0, 0, 0};
   int flags = 0;
   bool alive = false;
@@ -903,12 +904,13 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
   const bool social = (flags & SMX_F_SOCIAL) != 0;
   const bool mine = valid && alive && !social && (!a.first_only || first);
   bool done = false;
+  int new_flags = flags;  // what the commit kernel makes the vehicle's flags word after this pass
   if (valid && alive && social && first) {
     // nothing to observe: its rows read as an absent agent's
     zero_dense_rows(a, gid);
     o.active[gid] = 0;
     o.done[gid] = 0;
-    a.st.flags[gid] = flags & ~SMX_F_FIRST;
+    new_flags = flags & ~SMX_F_FIRST;
   }
   if (mine) {
     const double px = s.x, py = s.y;
@@ -1110,13 +1112,9 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
 
     // ---- teardown (smarts.py:314, 329-363)
     flags &= ~SMX_F_FIRST;
-    if (done) {
-      flags &= ~SMX_F_ALIVE;
-      atomicAdd(&env_new_done[env_local], 1);
-    }
+    if (done) flags &= ~SMX_F_ALIVE;
     a.st.steps[gid] = steps;
-    // the trip-meter bit belongs to k_waypoints (same launch sequence, earlier kernel)
-    a.st.flags[gid] = (flags & ~SMX_F_TRIP_HAS_WP) | (a.st.flags[gid] & SMX_F_TRIP_HAS_WP);
+    new_flags = flags;  // applied by k_commit: the waypoints role of this launch still reads the old word
     o.active[gid] = done ? 0 : 1;
     if (!a.keep_reward_done) {
       o.done[gid] = done ? 1 : 0;
@@ -1134,9 +1132,42 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
       o.active[gid] = 0;
     }
   }
-  __syncthreads();
+  if (valid) a.st.facts_i32[(size_t)SMX_FI_FLAGS_NEXT * total + gid] = new_flags;
+}
+
+// =================================================================================
+// k_commit: the end of a pass, after every sensor role has read the old flags: apply the flags the
+// observe role decided (teardown of done agents, smarts.py:314, 329-363), per-env done count and
+// dones["__all__"] (hiway_env.py:258-261), and the auto-reset respawn (parallel_env.py:303-309) —
+// the reset pass that follows builds the first observations of the restarted envs.
+// One thread per vehicle, whole envs per workgroup.
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
+  __shared__ int env_new_done[SMX_BLOCK];
   __shared__ int env_respawn[SMX_BLOCK];
-  if (slot == 0 && env_local < epb) env_respawn[env_local] = 0;
+  __shared__ int env_first_alive[SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const smx_outputs& o = a.out;
+  const int n_veh = c.num_vehicles;
+  const int epb = SMX_BLOCK / n_veh;
+  const int local = threadIdx.x;
+  const int env_local = local / n_veh;
+  const int slot = local - env_local * n_veh;
+  const int env = blockIdx.x * epb + env_local;
+  const bool valid = (env_local < epb) && (env < c.num_envs);
+  const size_t total = (size_t)c.num_envs * n_veh;
+  const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
+  env_new_done[local] = 0;
+  env_respawn[local] = 0;
+  __syncthreads();
+  if (valid) {
+    const int old_flags = a.st.flags[gid];
+    const int new_flags = a.st.facts_i32[(size_t)SMX_FI_FLAGS_NEXT * total + gid];
+    a.st.flags[gid] = new_flags;
+    if ((old_flags & SMX_F_ALIVE) && !(new_flags & SMX_F_ALIVE)) atomicAdd(&env_new_done[env_local], 1);
+    if (slot == 0) env_first_alive[env_local] = (new_flags & SMX_F_ALIVE) ? 1 : 0;
+  }
+  __syncthreads();
   if (valid && slot == 0) {
     if (!a.first_only) {
       int dcnt = a.st.env_done_count[env] + env_new_done[env_local];
@@ -1147,12 +1178,10 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
       a.st.env_reset_pending[env] = 0;
       env_respawn[env_local] = (all_done && c.auto_reset) ? 1 : 0;
     } else if (!a.keep_reward_done) {
-      if (a.st.env_done_count[env] == 0 && pose[env_local * n_veh].alive) o.env_done[env] = 0;
+      if (a.st.env_done_count[env] == 0 && env_first_alive[env_local]) o.env_done[env] = 0;
     }
   }
   __syncthreads();
-  // ---- auto-reset (parallel_env.py:303-309): an env whose agents are all done starts its next
-  // episode here; the reset pass that follows this kernel builds the first observations
   const bool respawn = valid && env_respawn[env_local] != 0;
   int next_episode = 0;
   if (respawn) {
@@ -1238,11 +1267,11 @@ struct LidarPose {
   int alive;
 };
 
-__global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
+__device__ __forceinline__ void lidar_role(const KernelArgs& a, const int block) {
   __shared__ LidarPose mates[SMX_BLOCK];
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = blockIdx.x;
+  const size_t gid = (size_t)block;
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   const bool live = (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
@@ -1341,6 +1370,24 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) {
       a.out.lidar_point[q * 3 + 1] = inf;
       a.out.lidar_point[q * 3 + 2] = inf;
     }
+  }
+}
+
+// =================================================================================
+// k_sensors: the observation of a pass as ONE launch whose workgroups take different roles —
+// waypoint paths + trip meter (4 lanes / vehicle), the rest of Sensors.observe (1 lane / vehicle,
+// whole envs per workgroup) and, if enabled, lidar (1 wavefront / vehicle).  The roles read the
+// same pose / flags / facts and write disjoint outputs, so they overlap in time; the flags word
+// itself only changes in k_commit.
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
+  const int b = (int)blockIdx.x;
+  if (b < a.wp_blocks) {
+    waypoints_role(a, b);
+  } else if (b < a.wp_blocks + a.obs_blocks) {
+    observe_role(a, b - a.wp_blocks);
+  } else {
+    lidar_role(a, b - a.wp_blocks - a.obs_blocks);
   }
 }
 
@@ -1715,6 +1762,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   }
 #define SMX_PHASE_END(p) \
   if (phased) SMX_HIP(hipEventRecord(ph[(p) + 1], stream))
+  const int lidar_blocks = (c.sensors & SMX_SENSOR_LIDAR) ? (int)total : 0;
+  a.wp_blocks = wp_blocks;
+  a.obs_blocks = obs_blocks;
+  const unsigned sensor_blocks = (unsigned)(wp_blocks + obs_blocks + lidar_blocks);
   if (is_step) {
     hipLaunchKernelGGL(k_control, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_CONTROL);
@@ -1723,12 +1774,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     if (c.sensors & SMX_SENSOR_OGM)
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, a);
     SMX_PHASE_END(SMX_PHASE_OGM);
-    if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, a);
-    SMX_PHASE_END(SMX_PHASE_LIDAR);
-    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
-    SMX_PHASE_END(SMX_PHASE_WAYPOINTS);
-    hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
-    SMX_PHASE_END(SMX_PHASE_OBSERVE);
+    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_SENSORS);
+    hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    SMX_PHASE_END(SMX_PHASE_COMMIT);
   }
   if (!is_step || c.auto_reset) {
     KernelArgs r = a;
@@ -1736,16 +1785,15 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     r.keep_reward_done = is_step ? 1 : 0;
     r.reset_all = (!is_step && mask == nullptr) ? 1 : 0;
     r.env_mask = is_step ? nullptr : mask;
-    if (!is_step) {  // in a step, k_observe has already respawned the envs that ended
+    if (!is_step) {  // in a step, k_commit has already respawned the envs that ended
       hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
       hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     }
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
     if (c.sensors & SMX_SENSOR_OGM)
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, r);
-    if (c.sensors & SMX_SENSOR_LIDAR) hipLaunchKernelGGL(k_lidar, dim3((unsigned)total), dim3(SMX_BLOCK), 0, stream, r);
-    hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, r);
-    hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
   if (phased) {

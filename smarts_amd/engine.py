@@ -358,8 +358,10 @@ class BatchedSim:
         }
         if self.cfg.ogm:
             kb["ogm"] = 3 * 8 + 4 + o["ogm"]
-        if self.cfg.lidar is not None:
-            kb["lidar"] = 3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]
+        lidar = (3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]) if self.cfg.lidar is not None else 0
+        # k_sensors runs the waypoints, observe and lidar roles in one launch; k_commit applies the flags
+        kb["sensors"] = kb.pop("waypoints") + kb.pop("observe") + lidar
+        kb["commit"] = 3 * 4
         return kb
 
     def reset(self, env_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
