@@ -50,7 +50,7 @@ struct KernelArgs {
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
   int debug_skip;
-  int wp_blocks, obs_blocks;  // k_sensors: workgroups of the waypoints / observe roles (lidar takes the rest)
+  int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
   int scan_split;  // k_scan: 1 = the two halves run as separate workgroups (small batches), 0 = one after the other
 };
 
@@ -1205,11 +1205,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
 // oriented chassis rectangle; view centred on the vehicle, +row = behind, row 0 = ahead
 // (np.flipud, sensors.py:748), extent width*res x height*res (renderer.py:384-385).
 // =================================================================================
-__global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) {
+__device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
   extern __shared__ __align__(16) unsigned char tile[];
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = blockIdx.x;
+  const size_t gid = (size_t)block;
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   const bool live = (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
@@ -1376,7 +1376,7 @@ __device__ __forceinline__ void lidar_role(const KernelArgs& a, const int block)
 // =================================================================================
 // k_sensors: the observation of a pass as ONE launch whose workgroups take different roles —
 // waypoint paths + trip meter (4 lanes / vehicle), the rest of Sensors.observe (1 lane / vehicle,
-// whole envs per workgroup) and, if enabled, lidar (1 wavefront / vehicle).  The roles read the
+// whole envs per workgroup) and, if enabled, lidar and OGM (1 wavefront / vehicle each).  The roles read the
 // same pose / flags / facts and write disjoint outputs, so they overlap in time; the flags word
 // itself only changes in k_commit.
 // =================================================================================
@@ -1386,10 +1386,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
     waypoints_role(a, b);
   } else if (b < a.wp_blocks + a.obs_blocks) {
     observe_role(a, b - a.wp_blocks);
-  } else {
+  } else if (b < a.wp_blocks + a.obs_blocks + a.lidar_blocks) {
     lidar_role(a, b - a.wp_blocks - a.obs_blocks);
+  } else {
+    ogm_role(a, b - a.wp_blocks - a.obs_blocks - a.lidar_blocks);
   }
 }
+
+// the OGM role alone, for tiles too large to ride along as dynamic LDS of every k_sensors workgroup
+__global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) { ogm_role(a, (int)blockIdx.x); }
 
 // =================================================================================
 // k_reset: SMARTS.reset (smarts.py:365-460) for the selected envs — vehicles re-created at their
@@ -1726,9 +1731,12 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.scan_split = 0;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
-  // measured on MI355X: separate workgroups win at 8 k vehicles (54 vs 70 us) and still at 131 k
-  // (0.40 vs 0.52 ms for the back-to-back form), so the halves are always split
-  const int scan_split = 1;
+  // Small batches are bound by one wavefront's latency, so independent work is spread over more
+  // workgroups (k_scan halves as separate roles: 54 vs 70 us at 8 k vehicles; the OGM role inside
+  // k_sensors); large batches are bound by throughput, where the same tricks cost occupancy
+  // (131 k vehicles: k_scan 0.69 vs 0.52 ms split vs back-to-back, OGM inside k_sensors +6 %).
+  const bool small_batch = total < 32768;
+  const int scan_split = small_batch ? 1 : 0;
   a.scan_split = scan_split;
   const int scan_blocks = (scan_split ? 2 : 1) * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
   const int vpb = SMX_BLOCK / SMX_WP_LANES;
@@ -1763,18 +1771,24 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
 #define SMX_PHASE_END(p) \
   if (phased) SMX_HIP(hipEventRecord(ph[(p) + 1], stream))
   const int lidar_blocks = (c.sensors & SMX_SENSOR_LIDAR) ? (int)total : 0;
+  // the OGM tile is dynamic LDS: on small batches, up to 16 KiB, it rides along in k_sensors; otherwise
+  // the OGM role gets its own launch
+  const size_t ogm_bytes = (c.sensors & SMX_SENSOR_OGM) ? (size_t)c.ogm_width * c.ogm_height : 0;
+  const bool ogm_inline = small_batch && ogm_bytes > 0 && ogm_bytes <= 16 * 1024;
+  const bool ogm_alone = ogm_bytes > 0 && !ogm_inline;
   a.wp_blocks = wp_blocks;
   a.obs_blocks = obs_blocks;
-  const unsigned sensor_blocks = (unsigned)(wp_blocks + obs_blocks + lidar_blocks);
+  a.lidar_blocks = lidar_blocks;
+  const unsigned sensor_blocks = (unsigned)(wp_blocks + obs_blocks + lidar_blocks + (ogm_inline ? (int)total : 0));
+  const size_t sensor_lds = ogm_inline ? ogm_bytes : 0;
   if (is_step) {
     hipLaunchKernelGGL(k_control, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_CONTROL);
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_SCAN);
-    if (c.sensors & SMX_SENSOR_OGM)
-      hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, a);
+    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, a);
     SMX_PHASE_END(SMX_PHASE_OGM);
-    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, a);
     SMX_PHASE_END(SMX_PHASE_SENSORS);
     hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_COMMIT);
@@ -1790,9 +1804,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     }
     hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
-    if (c.sensors & SMX_SENSOR_OGM)
-      hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), (size_t)c.ogm_width * c.ogm_height, stream, r);
-    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, r);
+    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, r);
     hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());

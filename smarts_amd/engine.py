@@ -356,11 +356,14 @@ class BatchedSim:
             "observe": state + facts + 12 * 8 + sum(
                 v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar"))),
         }
-        if self.cfg.ogm:
-            kb["ogm"] = 3 * 8 + 4 + o["ogm"]
+        ogm = (3 * 8 + 4 + o["ogm"]) if self.cfg.ogm else 0
+        ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
+                      and self.E * self.N < 32768)  # smx_kernels.hip enqueue(): small batches only
+        if self.cfg.ogm and not ogm_inline:
+            kb["ogm"] = ogm  # its own launch
         lidar = (3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]) if self.cfg.lidar is not None else 0
         # k_sensors runs the waypoints, observe and lidar roles in one launch; k_commit applies the flags
-        kb["sensors"] = kb.pop("waypoints") + kb.pop("observe") + lidar
+        kb["sensors"] = kb.pop("waypoints") + kb.pop("observe") + lidar + (ogm if ogm_inline else 0)
         kb["commit"] = 3 * 4
         return kb
 

@@ -57,7 +57,8 @@ def test_teacher_forced_ticks(name, E, N, T, seed, nets, compiled_maps):
 
 
 @pytest.mark.parametrize("name,E,N,T,seed,sensor", [("loop", 2, 32, 20, 31, "ogm"), ("minicity", 2, 32, 20, 32, "lidar"),
-                                                     ("4lane", 2, 16, 12, 33, "basic_lidar+ogm")])
+                                                     ("4lane", 2, 16, 12, 33, "basic_lidar+ogm"),
+                                                     ("loop", 1, 8, 4, 34, "default_ogm")])
 def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps):
     """BASELINE.json configs[3] (OGM 64 x 64 over 50 m) and configs[4] (100-ray planar lidar) at
     oracle-sized batches: grids and hit flags bit-exact, hit points to 1e-9."""
@@ -66,7 +67,9 @@ def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps)
     from smarts_amd.lidar import BasicLidar, Planar100
 
     kw = {}
-    if "ogm" in sensor:
+    if sensor == "default_ogm":
+        kw.update(ogm=True)  # agent_interface.py:42-51: 256 x 256 @ 50/256 — a 64 KiB tile, its own launch
+    elif "ogm" in sensor:
         kw.update(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
     if "lidar" in sensor:
         kw.update(lidar=BasicLidar if "basic" in sensor else Planar100)
@@ -74,7 +77,9 @@ def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps)
     d, o = _host(sim.reset()), ob.reset_observe()
     assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
     if "ogm" in sensor:
-        assert d["ogm"].reshape(E * N, 64, 64)[:, 31:33, 31:33].min() == 255  # own footprint at the centre
+        side = cfg.ogm_width
+        g = d["ogm"].reshape(E * N, side, side)
+        assert g[:, side // 2 - 1:side // 2 + 1, side // 2 - 1:side // 2 + 1].min() == 255  # own footprint at the centre
     rng = np.random.default_rng(seed)
     seen_hits = 0
     for t in range(T):
@@ -331,6 +336,35 @@ def test_full_size_properties(compiled_maps):
     assert np.isfinite(o1["ego_pos"].cpu().numpy()).all()
     for s in (sim, sim2, sim3):
         s.close()
+
+
+def test_large_batch_launch_strategy_agrees_with_small_batch(compiled_maps):
+    """From 32768 vehicles on, k_scan runs its halves back to back and the OGM role gets its own
+    launch (smx_kernels.hip enqueue()); a 4096 x 8 batch must compute what a 32-env slice of it
+    (small-batch strategy) computes."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps("4lane")
+    E, N, sub = 4096, 8, 32
+    spawns = make_spawns(cm, sub, N, episodes=1, seed=9)
+    big = np.tile(spawns, (1, E // sub, 1))  # the slice repeated: every env group sees the same worlds
+    kw = dict(num_vehicles=N, neighbors=True, nb_radius=50.0, ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
+    sim = BatchedSim(cm, SimConfig(num_envs=E, **kw), spawns=big)
+    sim2 = BatchedSim(cm, SimConfig(num_envs=sub, **kw), spawns=spawns)
+    rng = np.random.default_rng(9)
+    sim.reset(), sim2.reset()
+    for t in range(12):
+        a_small = _actions(rng, sub, N)
+        o1 = sim.step(torch.from_numpy(np.tile(a_small, (E // sub, 1))).cuda())
+        o2 = sim2.step(torch.from_numpy(a_small).cuda())
+    torch.cuda.synchronize()
+    for k in o2:
+        a, b = o1[k].cpu().numpy(), o2[k].cpu().numpy()
+        first, last = (a[:, :sub], a[:, E - sub:]) if k == "learner" else (a[:sub], a[E - sub:])
+        assert np.array_equal(first, b, equal_nan=True) and np.array_equal(last, b, equal_nan=True), k
+    sim.close(), sim2.close()
 
 
 def test_step_before_reset_raises(compiled_maps):
