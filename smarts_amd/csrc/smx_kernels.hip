@@ -51,7 +51,6 @@ struct KernelArgs {
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
   int debug_skip;
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
-  int scan_split;  // k_scan: 1 = the two halves run as separate workgroups (small batches), 0 = one after the other
 };
 
 #define SF(field) a.st.f64[(size_t)(field) * total + gid]
@@ -516,6 +515,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TACC(14, ts0, ts6);
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
@@ -523,14 +523,21 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   // the two halves of the scan are independent: on small batches they run as different workgroups
   // of one launch (even: road facts + lane heading, odd: lanepoint search + path seeds) and
   // overlap in time; on large ones every workgroup does both, one after the other
-  const int split = a.scan_split;
-  const size_t gid = ((size_t)(split ? (blockIdx.x >> 1) : blockIdx.x) * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
+  const size_t gid = ((size_t)(SPLIT ? (blockIdx.x >> 1) : blockIdx.x) * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
   const int rank = team_rank();
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
-  for (int role = split ? (int)(blockIdx.x & 1) : 0; role < 2; role += split ? 2 : 1) scan_role(a, m, c, gid, total, rank, flags, role);
+  if (SPLIT) {
+    if (blockIdx.x & 1)
+      scan_role(a, m, c, gid, total, rank, flags, 1);
+    else
+      scan_role(a, m, c, gid, total, rank, flags, 0);
+  } else {
+    scan_role(a, m, c, gid, total, rank, flags, 0);
+    scan_role(a, m, c, gid, total, rank, flags, 1);
+  }
 }
 
 // =================================================================================
@@ -1393,8 +1400,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
   }
 }
 
-// the OGM role alone, for tiles too large to ride along as dynamic LDS of every k_sensors workgroup
+// single-role launches: large batches (each role then keeps its own register / LDS footprint and
+// occupancy) and OGM tiles too large to ride along as dynamic LDS of every k_sensors workgroup
 __global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) { ogm_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
 
 // =================================================================================
 // k_reset: SMARTS.reset (smarts.py:365-460) for the selected envs — vehicles re-created at their
@@ -1728,7 +1739,6 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.heading_gain_pos = h->heading_gain_pos;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
-  a.scan_split = 0;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
   // Small batches are bound by one wavefront's latency, so independent work is spread over more
@@ -1737,7 +1747,6 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // (131 k vehicles: k_scan 0.69 vs 0.52 ms split vs back-to-back, OGM inside k_sensors +6 %).
   const bool small_batch = total < 32768;
   const int scan_split = small_batch ? 1 : 0;
-  a.scan_split = scan_split;
   const int scan_blocks = (scan_split ? 2 : 1) * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
   const int vpb = SMX_BLOCK / SMX_WP_LANES;
   const int wp_blocks = (int)((total + vpb - 1) / vpb);
@@ -1781,17 +1790,30 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.lidar_blocks = lidar_blocks;
   const unsigned sensor_blocks = (unsigned)(wp_blocks + obs_blocks + lidar_blocks + (ogm_inline ? (int)total : 0));
   const size_t sensor_lds = ogm_inline ? ogm_bytes : 0;
+  // one pass of scan + sensors + commit (the tick's, then the reset pass restricted to new vehicles)
+  auto observation_pass = [&](const KernelArgs& k, bool phases) {
+    if (scan_split)
+      hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    else
+      hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
+    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
+    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_OGM + 1], stream);
+    if (small_batch) {
+      hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, k);
+    } else {
+      hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    }
+    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SENSORS + 1], stream);
+    hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_COMMIT + 1], stream);
+  };
   if (is_step) {
     hipLaunchKernelGGL(k_control, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
     SMX_PHASE_END(SMX_PHASE_CONTROL);
-    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, a);
-    SMX_PHASE_END(SMX_PHASE_SCAN);
-    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, a);
-    SMX_PHASE_END(SMX_PHASE_OGM);
-    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, a);
-    SMX_PHASE_END(SMX_PHASE_SENSORS);
-    hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, a);
-    SMX_PHASE_END(SMX_PHASE_COMMIT);
+    observation_pass(a, true);
   }
   if (!is_step || c.auto_reset) {
     KernelArgs r = a;
@@ -1803,10 +1825,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
       hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     }
-    hipLaunchKernelGGL(k_scan, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, r);
-    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, r);
-    hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, r);
-    hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    observation_pass(r, false);
   }
   SMX_HIP(hipGetLastError());
   if (phased) {
