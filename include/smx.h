@@ -91,7 +91,8 @@ enum {
   SMX_ACTION_SPACE_LANE = 0,
   SMX_ACTION_SPACE_CONTINUOUS = 1,
   SMX_ACTION_SPACE_ACTUATOR_DYNAMIC = 2,
-  SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED = 3
+  SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED = 3,
+  SMX_ACTION_SPACE_TRAJECTORY = 4 /* smx_step_trajectory: PD tracking (trajectory_tracking_controller.py:176-331) */
 };
 
 typedef struct smx_config {
@@ -319,6 +320,13 @@ int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const
 /* The same tick for the float action spaces: actions[E*N][3] (float32, device). */
 int smx_step_continuous(smx_handle h, const float* actions_dev, const smx_state* st, const smx_spawns* sp,
                         const smx_outputs* out, void* hip_stream);
+/* The same tick for ActionSpaceType.Trajectory.  trajectories[E*N][4][SMX_TRAJ_COLS] (float64, device):
+ * rows x, y, heading, speed; columns 0..9 = the first ten points, column 10 = the LAST point of the
+ * trajectory — all the PD controller reads; counts[E*N] (int32, device) = the trajectory's true
+ * length, 0 = no action this tick. */
+#define SMX_TRAJ_COLS 11
+int smx_step_trajectory(smx_handle h, const double* trajectories_dev, const int32_t* counts_dev, const smx_state* st,
+                        const smx_spawns* sp, const smx_outputs* out, void* hip_stream);
 int smx_sync(smx_handle h, void* hip_stream);
 /* Device-side timing: while enabled, every smx_step is bracketed by a hipEvent pair recorded on
  * the stream it is launched on (no synchronisation).  smx_read_step_ms waits for the recorded

@@ -229,3 +229,145 @@ def perform_lane_following(road_map, veh, state, dt, target_speed=12.5, lane_cha
 # path ever reads it back), and its update goes through the road map's shared
 # ``_WaypointsCache`` keyed by lane *index* (sumo_road_network.py:1229-1276), which
 # makes it depend on which other agent queried last.  See DESIGN.md "Deviations".
+
+
+# ---------------------------------------------------------------------------------------------
+# ActionSpaceType.Trajectory: TrajectoryTrackingController.perform_trajectory_tracking_PD
+# (trajectory_tracking_controller.py:230-331) with its helpers (:333-441) and the sedan's
+# controller parameters (models/controller_parameters.yaml:1-16).
+# ---------------------------------------------------------------------------------------------
+SEDAN_CONTROL = dict(
+    final_heading_gain=0.15, final_lateral_gain=4.65, final_steering_filter_constant=23.5, throttle_filter_constant=22.5,
+    velocity_gain=5.1, velocity_integral_gain=0, traction_gain=6, final_lateral_error_derivative_gain=0.3,
+    final_heading_error_derivative_gain=3.1, initial_look_ahead_distant=6, derivative_activation=1,
+    speed_reduction_activation=1, velocity_damping_gain=0.001, windup_gain=0.01,
+)
+
+
+class TrajectoryTrackingControllerState:
+    """trajectory_tracking_controller.py:117-129."""
+
+    def __init__(self):
+        self.heading_error_gain = None
+        self.lateral_error_gain = None
+        self.heading_error = 0
+        self.lateral_error = 0
+        self.velocity_error = 0
+        self.integral_velocity_error = 0
+        self.integral_windup_error = 0
+        self.steering_state = 0
+        self.throttle_state = 0
+
+
+def _heading_lateral_error(veh, trajectory, initial_look_ahead_distant, speed_reduction_activation):
+    """:398-441."""
+    heading_error = rm.min_angles_difference_signed((veh.heading % (2 * math.pi)), trajectory[2][0])
+    look_ahead_points = initial_look_ahead_distant
+    if abs(curvature_calculation(trajectory, 4)) < 30 and speed_reduction_activation:
+        initial_look_ahead_distant = 1
+        look_ahead_points = 1
+    k = min([look_ahead_points, len(trajectory[2]) - 1])
+    path_vector = rm.radians_to_vec(trajectory[2][k])
+    look_ahead_pt = [
+        veh.position[0] - initial_look_ahead_distant * math.sin(veh.heading),
+        veh.position[1] + initial_look_ahead_distant * math.cos(veh.heading),
+    ]
+    lateral_error = rm.signed_dist_to_line(look_ahead_pt, [trajectory[0][k], trajectory[1][k]], path_vector)
+    return heading_error, lateral_error
+
+
+def _raw_throttle_feedback(veh, state, trajectory, velocity_gain, velocity_integral_gain, integral_velocity_error,
+                           velocity_damping_gain, windup_gain, traction_gain, speed_reduction_activation,
+                           throttle_filter_constant, dt_sec):
+    """:333-395."""
+    desired_speed = trajectory[3][-1]
+    absolute_ahead_curvature = abs(curvature_calculation(trajectory, 4))
+    if absolute_ahead_curvature < 30 and speed_reduction_activation:
+        desired_speed = np.clip(0.8 * desired_speed, 0, 8.3)
+    elif absolute_ahead_curvature < 100 and speed_reduction_activation:
+        desired_speed *= 0.8
+    velocity_error = veh.speed - desired_speed
+    velocity_error_damping_term = (velocity_error - state.velocity_error) / dt_sec
+    raw_throttle = 3.6 * (
+        -0.5 * velocity_gain * velocity_error
+        - velocity_integral_gain * (integral_velocity_error + windup_gain * state.integral_windup_error)
+        - velocity_damping_gain * velocity_error_damping_term
+    )
+    state.velocity_error = velocity_error
+    state.integral_windup_error = np.clip(raw_throttle, -1, 1) - raw_throttle
+    state.throttle_state = rm.low_pass_filter(
+        raw_throttle, state.throttle_state, throttle_filter_constant, dt_sec,
+        raw_value=-traction_gain * abs(veh.longitudinal_lateral_speed[1]),
+    )
+    return state.throttle_state, desired_speed
+
+
+def perform_trajectory_tracking_pd(trajectory, veh, state, dt_sec, params=SEDAN_CONTROL):
+    """:230-331.  ``trajectory`` = (xs, ys, headings, speeds); returns (throttle, brake, steering)."""
+    final_steering_filter_constant = params["final_steering_filter_constant"]
+    throttle_filter_constant = params["throttle_filter_constant"]
+    lateral_gain = 0.61
+    heading_gain = 0.01
+    lateral_error_derivative_gain = 0.15
+    heading_error_derivative_gain = 0.5
+    normalized_speed = np.clip((3.6 * trajectory[3][0] - 20) / (80 - 20), 0, 1)
+    if veh.speed > 70 / 3.6:  # adjust_gains_for_normalized_speed is False in the reference (:262)
+        lateral_gain = 1.51
+        heading_error_derivative_gain = 0.1
+    steering_filter_constant = rm.lerp(12, final_steering_filter_constant, normalized_speed)
+    if abs(rm.min_angles_difference_signed(trajectory[2][-1], trajectory[2][0])) > 2:
+        throttle_filter_constant = 2.5
+    if abs(curvature_calculation(trajectory, 0, num_points=3)) < 150:
+        heading_gain = 0.05
+        lateral_error_derivative_gain = 0.015
+        heading_error_derivative_gain = 0.05
+    heading_error, lateral_error = _heading_lateral_error(
+        veh, trajectory, params["initial_look_ahead_distant"], params["speed_reduction_activation"])
+    curvature_radius = curvature_calculation(trajectory)
+    z_yaw = veh.angular_velocity[2]
+    derivative_term = (+heading_error_derivative_gain * z_yaw
+                       + lateral_error_derivative_gain * (lateral_error - state.lateral_error) / dt_sec)
+    steering_feed_forward_term = 0.1 * (1 / curvature_radius) * (veh.speed) ** 2
+    steering_raw = np.clip(
+        params["derivative_activation"] * derivative_term + math.degrees(heading_gain * (heading_error))
+        + 1 * lateral_gain * lateral_error - steering_feed_forward_term, -1, 1)
+    state.steering_state = rm.low_pass_filter(steering_raw, state.steering_state, steering_filter_constant, dt_sec)
+    raw_throttle, desired_speed = _raw_throttle_feedback(
+        veh, state, trajectory, params["velocity_gain"], params["velocity_integral_gain"], state.integral_velocity_error,
+        params["velocity_damping_gain"], params["windup_gain"], params["traction_gain"],
+        params["speed_reduction_activation"], throttle_filter_constant, dt_sec)
+    if raw_throttle > 0:
+        brake_norm, throttle_norm = 0, np.clip(raw_throttle, 0, 1)
+    else:
+        brake_norm, throttle_norm = np.clip(-raw_throttle, 0, 1), 0
+    state.heading_error = heading_error
+    state.lateral_error = lateral_error
+    state.integral_velocity_error += (veh.speed - desired_speed) * dt_sec
+    return float(throttle_norm), float(brake_norm), float(state.steering_state)
+
+
+class PackedTrajectory:
+    """The form a trajectory travels in (include/smx.h smx_step_trajectory): the controller reads
+    points 0..9, the last point and the length, nothing else.  Indexing mirrors a full list."""
+
+    def __init__(self, row, n):
+        self.row, self.n = row, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        if i == self.n - 1:
+            return float(self.row[10]) if self.n > 10 else float(self.row[i])
+        if i >= 10:
+            raise IndexError(f"point {i} of a packed trajectory is not carried")
+        return float(self.row[i])
+
+
+def unpack_trajectory(packed, n):
+    """``packed``: [4][11] (x, y, heading, speed rows; column 10 = the last point)."""
+    return [PackedTrajectory(packed[r], n) for r in range(4)]

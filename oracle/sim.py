@@ -253,14 +253,20 @@ class OracleEnv:
             none = action is None
             if not none and space == "Lane" and not isinstance(action, str) and int(action) < 0:
                 none = True
-            if not none and space != "Lane" and np.isnan(float(action[0])):
+            if not none and space == "Trajectory" and len(action[0]) == 0:
+                none = True
+            if not none and space not in ("Lane", "Trajectory") and np.isnan(float(action[0])):
                 none = True
             if none:
                 # no action this tick (controllers/__init__.py:87-88): wheel torques last one
                 # physics step only, the steer motor keeps its target
                 ag.body.control(throttle=0.0, brake=0.0, steering=ag.ctrl.steering_state)
                 continue
-            if space == "Continuous":  # controllers/__init__.py:94-99
+            if space == "Trajectory":  # controllers/__init__.py:104-110
+                if not isinstance(ag.ctrl, ctl.TrajectoryTrackingControllerState):
+                    ag.ctrl = ctl.TrajectoryTrackingControllerState()  # ControllerState.from_action_space
+                thr, brk, steer = ctl.perform_trajectory_tracking_pd(action, ag.body, ag.ctrl, self.dt)
+            elif space == "Continuous":  # controllers/__init__.py:94-99
                 thr, brk, steer = (float(np.clip(action[0], 0.0, 1.0)), float(np.clip(action[1], 0.0, 1.0)),
                                    float(np.clip(action[2], -1, 1)))
                 ag.ctrl.steering_state = steer

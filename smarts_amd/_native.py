@@ -22,7 +22,8 @@ DONE_ON_SHOULDER, DONE_WRONG_WAY, DONE_NOT_MOVING = 8, 16, 32
 EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way", "not_moving", "reached_goal",
                "reached_max_episode_steps", "agents_alive_done"]
 EV = {name.upper(): i for i, name in enumerate(EVENT_NAMES)}
-ACTION_SPACES = {"Lane": 0, "Continuous": 1, "ActuatorDynamic": 2, "LaneWithContinuousSpeed": 3}
+ACTION_SPACES = {"Lane": 0, "Continuous": 1, "ActuatorDynamic": 2, "LaneWithContinuousSpeed": 3, "Trajectory": 4}
+TRAJ_COLS = 11
 PHASES = ["control", "scan", "ogm", "sensors", "commit", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
@@ -92,7 +93,7 @@ class SmxOutputs(C.Structure):
 
 
 EXPORTS = [
-    "smx_create", "smx_load_map", "smx_step_continuous", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
+    "smx_create", "smx_load_map", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
 ]
 
@@ -143,6 +144,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_read_step_ms.restype = C.c_int
     lib.smx_step_continuous.argtypes = [h, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
     lib.smx_step_continuous.restype = C.c_int
+    lib.smx_step_trajectory.argtypes = [h, _p, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
+    lib.smx_step_trajectory.restype = C.c_int
     lib.smx_read_phase_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]
     lib.smx_read_phase_ms.restype = C.c_int
     lib.smx_set_timing.argtypes = [h, C.c_int]

@@ -43,6 +43,8 @@ struct KernelArgs {
   smx_outputs out;
   const int8_t* actions;
   const float* actions_f32;  // float action spaces: [E*N][3]
+  const double* traj;        // Trajectory space: [E*N][4][SMX_TRAJ_COLS]
+  const int32_t* traj_n;     // ... true lengths, 0 = no action
   const uint8_t* env_mask;  // k_reset: explicit mask (NULL = use env_reset_pending / all)
   const double* lidar_rays;
   int first_only;           // restrict to vehicles carrying SMX_F_FIRST (reset observations)
@@ -228,6 +230,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   if (space == SMX_ACTION_SPACE_LANE) {
     action = a.actions[gid];
     has_action = action >= 0;
+  } else if (space == SMX_ACTION_SPACE_TRAJECTORY) {
+    has_action = a.traj_n[gid] > 0;
   } else {
     act0 = a.actions_f32[gid * 3 + 0];
     act1 = a.actions_f32[gid * 3 + 1];
@@ -241,7 +245,14 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   co.steering = cs.steer;
   const bool lane_following =
       space == SMX_ACTION_SPACE_LANE || space == SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED;
-  if (has_action && !lane_following) {
+  if (has_action && space == SMX_ACTION_SPACE_TRAJECTORY) {
+    if (p0 == 0) {
+      PackedTraj t;
+      t.p = a.traj + gid * (size_t)(4 * SMX_TRAJ_COLS);
+      t.n = a.traj_n[gid];
+      co = trajectory_tracking_pd(s, cs, c.dt, t);
+    }
+  } else if (has_action && !lane_following) {
     if (space == SMX_ACTION_SPACE_CONTINUOUS) {
       // :94-99
       co.throttle = clip_ref((double)act0, 0.0, 1.0);
@@ -1559,7 +1570,7 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
     return fail(h, SMX_ERR_INVALID, "num_social must leave at least one agent slot");
   if (c.num_social > 0 && !(c.social_speed_factor >= 0.0))
     return fail(h, SMX_ERR_INVALID, "social_speed_factor must be >= 0");
-  if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED)
+  if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_TRAJECTORY)
     return fail(h, SMX_ERR_INVALID, "unknown action_space");
   if ((c.sensors & SMX_SENSOR_OGM) &&
       (c.ogm_width < 1 || c.ogm_height < 1 || (c.ogm_width * c.ogm_height) % 16 != 0 ||
@@ -1711,16 +1722,23 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   return SMX_OK;
 }
 
-static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const float* actions_f32, const uint8_t* mask,
-                   const smx_state* st,
+static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const float* actions_f32, const double* traj,
+                   const int32_t* traj_n, const uint8_t* mask, const smx_state* st,
                    const smx_spawns* sp, const smx_outputs* out, void* stream_) {
   if (!h) return SMX_ERR_INVALID;
   if (!h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_load_map has not been called");
   int rc = check_buffers(h, st, sp, out);
   if (rc != SMX_OK) return rc;
-  if (is_step && !actions && !actions_f32) return fail(h, SMX_ERR_INVALID, "null actions");
-  if (is_step && (h->cfg.action_space == SMX_ACTION_SPACE_LANE) != (actions != nullptr))
-    return fail(h, SMX_ERR_INVALID, "smx_step takes the Lane action space, smx_step_continuous the float ones");
+  if (is_step) {
+    const int sp_ = h->cfg.action_space;
+    const bool ok = sp_ == SMX_ACTION_SPACE_LANE ? actions != nullptr
+                    : sp_ == SMX_ACTION_SPACE_TRAJECTORY ? (traj != nullptr && traj_n != nullptr)
+                                                         : actions_f32 != nullptr;
+    if (!ok)
+      return fail(h, SMX_ERR_INVALID,
+                  "actions do not match cfg.action_space (smx_step: Lane, smx_step_trajectory: Trajectory, "
+                  "smx_step_continuous: the float spaces)");
+  }
   hipStream_t stream = (hipStream_t)stream_;
   const smx_config& c = h->cfg;
   KernelArgs a;
@@ -1731,6 +1749,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.out = *out;
   a.actions = actions;
   a.actions_f32 = actions_f32;
+  a.traj = traj;
+  a.traj_n = traj_n;
   a.env_mask = mask;
   a.lidar_rays = h->lidar_rays;
   a.first_only = 0;
@@ -1842,17 +1862,22 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
 
 extern "C" int smx_reset(smx_handle h, const uint8_t* env_mask_dev, const smx_state* st, const smx_spawns* sp,
                          const smx_outputs* out, void* hip_stream) {
-  return enqueue(h, false, nullptr, nullptr, env_mask_dev, st, sp, out, hip_stream);
+  return enqueue(h, false, nullptr, nullptr, nullptr, nullptr, env_mask_dev, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_step(smx_handle h, const int8_t* actions_dev, const smx_state* st, const smx_spawns* sp,
                         const smx_outputs* out, void* hip_stream) {
-  return enqueue(h, true, actions_dev, nullptr, nullptr, st, sp, out, hip_stream);
+  return enqueue(h, true, actions_dev, nullptr, nullptr, nullptr, nullptr, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_step_continuous(smx_handle h, const float* actions_dev, const smx_state* st, const smx_spawns* sp,
                                    const smx_outputs* out, void* hip_stream) {
-  return enqueue(h, true, nullptr, actions_dev, nullptr, st, sp, out, hip_stream);
+  return enqueue(h, true, nullptr, actions_dev, nullptr, nullptr, nullptr, st, sp, out, hip_stream);
+}
+
+extern "C" int smx_step_trajectory(smx_handle h, const double* trajectories_dev, const int32_t* counts_dev,
+                                   const smx_state* st, const smx_spawns* sp, const smx_outputs* out, void* hip_stream) {
+  return enqueue(h, true, nullptr, nullptr, trajectories_dev, counts_dev, nullptr, st, sp, out, hip_stream);
 }
 
 extern "C" int smx_sync(smx_handle h, void* hip_stream) {

@@ -445,6 +445,120 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
 
 
 // ---------------------------------------------------------------------------------
+// ActionSpaceType.Trajectory: TrajectoryTrackingController.perform_trajectory_tracking_PD
+// (trajectory_tracking_controller.py:176-331) with calculate_raw_throttle_feedback (:333-395),
+// calculate_heading_lateral_error (:398-441), curvature_calculation (:444-473) and the sedan's
+// parameters (models/controller_parameters.yaml:1-16).  The controller reads trajectory points
+// 0..9, the last point and the length only, which is the form it travels in (smx.h).
+// Controller state reuse: lat_int = lateral_error, spd_int = integral_velocity_error, spd_err =
+// velocity_error, mcl_x = integral_windup_error, mcl_y = heading_error, steer / throttle = filters.
+// ---------------------------------------------------------------------------------
+struct PackedTraj {
+  const double* p;  // [4][SMX_TRAJ_COLS]: x, y, heading, speed rows; column 10 = the last point
+  int n;
+  __device__ __forceinline__ double at(int row, int i) const {
+    const double* r = p + row * SMX_TRAJ_COLS;
+    if (i == n - 1) return n > 10 ? r[10] : r[i];
+    return r[i];
+  }
+  __device__ __forceinline__ double last(int row) const { return at(row, n - 1); }
+};
+
+__device__ inline double traj_curvature(const PackedTraj& t, int offset, int num_points) {
+  if (t.n <= num_points + offset) return 1e20;
+  double hs = 0.0, ds = 0.0;
+  for (int i = 0; i < num_points; ++i) {
+    hs += min_angles_difference_signed(t.at(2, i + 1 + offset), t.at(2, i + offset));
+    const double ex = t.at(0, i + offset) - t.at(0, i + offset + 1), ey = t.at(1, i + offset) - t.at(1, i + offset + 1);
+    ds += fabs(sqrt(ex * ex + ey * ey));
+  }
+  if (hs == 0.0) return 1e20;
+  return ds / hs;
+}
+
+__device__ __forceinline__ double low_pass_filter_ref(double input, double prev, double filter_constant, double dt,
+                                                      double raw_value) {
+  // utils/math.py:219-244 (lower bound -1)
+  prev += dt * filter_constant * (input - prev);
+  return clip_ref(prev + raw_value, -1.0, 1.0);
+}
+
+__device__ inline ControlOut trajectory_tracking_pd(const VehState& s, CtrlState& cs, double dt, const PackedTraj& t) {
+  const HeadingTrig trig = heading_trig(s.heading);
+  const double speed = vehicle_speed(s, trig);
+  double lng, lat;
+  long_lat_speed(s, trig, lng, lat);
+  // models/controller_parameters.yaml, sedan.control
+  const double final_steering_filter_constant = 23.5, velocity_gain = 5.1, velocity_integral_gain = 0.0,
+               traction_gain = 6.0, derivative_activation = 1.0, velocity_damping_gain = 0.001, windup_gain = 0.01;
+  double throttle_filter_constant = 22.5;
+  const int initial_look_ahead = 6;
+  double lateral_gain = 0.61, heading_gain = 0.01, lateral_error_derivative_gain = 0.15,
+         heading_error_derivative_gain = 0.5;
+  const double normalized_speed = clip_ref((3.6 * t.at(3, 0) - 20.0) / (80.0 - 20.0), 0.0, 1.0);
+  if (speed > 70.0 / 3.6) {
+    lateral_gain = 1.51;
+    heading_error_derivative_gain = 0.1;
+  }
+  const double steering_filter_constant = lerp_ref(12.0, final_steering_filter_constant, normalized_speed);
+  if (fabs(min_angles_difference_signed(t.last(2), t.at(2, 0))) > 2.0) throttle_filter_constant = 2.5;
+  if (fabs(traj_curvature(t, 0, 3)) < 150.0) {
+    heading_gain = 0.05;
+    lateral_error_derivative_gain = 0.015;
+    heading_error_derivative_gain = 0.05;
+  }
+  const double ahead_curvature = fabs(traj_curvature(t, 4, 5));
+  // ---- calculate_heading_lateral_error
+  const double heading_error = min_angles_difference_signed(py_mod(s.heading, SMX_TWO_PI), t.at(2, 0));
+  int look = initial_look_ahead;
+  double look_dist = (double)initial_look_ahead;
+  if (ahead_curvature < 30.0) {  // speed_reduction_activation = 1
+    look = 1;
+    look_dist = 1.0;
+  }
+  const int k = look < t.n - 1 ? look : t.n - 1;
+  double pvx, pvy;
+  radians_to_vec(t.at(2, k), pvx, pvy);
+  const double lx = s.x - look_dist * trig.sh, ly = s.y + look_dist * trig.ch;
+  const double lateral_error = signed_dist_to_line(lx, ly, t.at(0, k), t.at(1, k), pvx, pvy);
+  // ---- steering
+  const double curvature_radius = traj_curvature(t, 0, 5);
+  const double derivative_term =
+      +heading_error_derivative_gain * s.r + lateral_error_derivative_gain * (lateral_error - cs.lat_int) / dt;
+  const double feed_forward = 0.1 * (1.0 / curvature_radius) * (speed * speed);
+  const double steering_raw = clip_ref(derivative_activation * derivative_term + (heading_gain * heading_error) * (180.0 / SMX_PI) +
+                                           1.0 * lateral_gain * lateral_error - feed_forward,
+                                       -1.0, 1.0);
+  cs.steer = low_pass_filter_ref(steering_raw, cs.steer, steering_filter_constant, dt, 0.0);
+  // ---- calculate_raw_throttle_feedback
+  double desired_speed = t.last(3);
+  if (ahead_curvature < 30.0)
+    desired_speed = clip_ref(0.8 * desired_speed, 0.0, 8.3);
+  else if (ahead_curvature < 100.0)
+    desired_speed *= 0.8;
+  const double velocity_error = speed - desired_speed;
+  const double damping = (velocity_error - cs.spd_err) / dt;
+  const double raw = 3.6 * (-0.5 * velocity_gain * velocity_error -
+                            velocity_integral_gain * (cs.spd_int + windup_gain * cs.mcl_x) - velocity_damping_gain * damping);
+  cs.spd_err = velocity_error;
+  cs.mcl_x = clip_ref(raw, -1.0, 1.0) - raw;
+  cs.throttle = low_pass_filter_ref(raw, cs.throttle, throttle_filter_constant, dt, -traction_gain * fabs(lat));
+  ControlOut out;
+  if (cs.throttle > 0.0) {
+    out.brake = 0.0;
+    out.throttle = clip_ref(cs.throttle, 0.0, 1.0);
+  } else {
+    out.brake = clip_ref(-cs.throttle, 0.0, 1.0);
+    out.throttle = 0.0;
+  }
+  out.steering = cs.steer;
+  cs.mcl_y = heading_error;
+  cs.lat_int = lateral_error;
+  cs.spd_int += (speed - desired_speed) * dt;
+  return out;
+}
+
+// ---------------------------------------------------------------------------------
 // Scripted social vehicle (include/smx.h smx_config.num_social): one tick of a kinematic lane
 // follower.  `lane` / `offset` locate it on a centre line (smx_shape_rec.cum is the arclength);
 // at a lane's end it continues on outgoing lane (slot + crossed) mod #outgoing, or stops there if

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass, field
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -85,6 +85,21 @@ class SimConfig:
         the trap fires once ``mission.start_time`` (0.1 s, plan.py:209) has *passed*
         (trap_manager.py:53-65), and ``reset`` spins ``step({})`` until then (smarts.py:426-434)."""
         return int(math.floor(0.1 / self.dt + 1e-9)) + 1
+
+
+def pack_trajectory(trajectory) -> Tuple[np.ndarray, int]:
+    """(xs, ys, headings, speeds) of any length -> ([4, 11] float64, length): the first ten points and,
+    in column 10, the last one — everything ``perform_trajectory_tracking_PD`` reads
+    (trajectory_tracking_controller.py:176-473)."""
+    n = len(trajectory[0])
+    if n < 1 or any(len(r) != n for r in trajectory):
+        raise ValueError("a trajectory is four equally long sequences (x, y, heading, speed)")
+    out = np.zeros((4, nat.TRAJ_COLS), dtype=np.float64)
+    for r in range(4):
+        head = np.asarray(trajectory[r][:10], dtype=np.float64)
+        out[r, :len(head)] = head
+        out[r, 10] = float(trajectory[r][n - 1])
+    return out, n
 
 
 def lane_heading(shape: np.ndarray, seg: int) -> float:
@@ -385,6 +400,8 @@ class BatchedSim:
         self._learner_k ^= 1
         self.out["learner"] = self._learner[self._learner_k]
         self._out.learner = self.out["learner"].data_ptr()
+        if self.cfg.action_space == "Trajectory":
+            raise ValueError("ActionSpaceType.Trajectory steps through step_trajectory(trajectories, counts)")
         if self.cfg.action_space == "Lane":
             if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
                 actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
@@ -406,6 +423,24 @@ class BatchedSim:
     def next_learner_block(self) -> torch.Tensor:
         """The learner block the NEXT ``step`` will write (see ``RewardDoneGather.release``)."""
         return self._learner[self._learner_k ^ 1]
+
+    def step_trajectory(self, trajectories: torch.Tensor, counts: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One tick in ActionSpaceType.Trajectory: ``trajectories`` float64 [E, N, 4, 11] in the packed
+        form of include/smx.h (``pack_trajectory``), ``counts`` int32 [E, N] (0 = no action)."""
+        if not self._was_reset:
+            raise RuntimeError("step() before reset()")
+        if self.cfg.action_space != "Trajectory":
+            raise ValueError("step_trajectory needs SimConfig(action_space='Trajectory')")
+        trajectories = trajectories.to(device=self.device, dtype=torch.float64).contiguous()
+        counts = counts.to(device=self.device, dtype=torch.int32).contiguous()
+        assert trajectories.shape == (self.E, self.N, 4, nat.TRAJ_COLS) and counts.shape == (self.E, self.N)
+        self._learner_k ^= 1
+        self.out["learner"] = self._learner[self._learner_k]
+        self._out.learner = self.out["learner"].data_ptr()
+        rc = self.lib.smx_step_trajectory(self.handle, trajectories.data_ptr(), counts.data_ptr(), C.byref(self._st),
+                                          C.byref(self._sp), C.byref(self._out), self._stream_ptr())
+        nat.check(self.lib, self.handle, rc, "smx_step_trajectory")
+        return self.out
 
     def set_timing(self, level):
         """0/False = off, 1/True = one event pair per smx_step, 2 = per-kernel phases."""

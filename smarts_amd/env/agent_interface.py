@@ -30,7 +30,7 @@ class ActionSpaceType(Enum):
 
 # action spaces with a device controller (include/smx.h SMX_ACTION_SPACE_*)
 DEVICE_ACTION_SPACES = (ActionSpaceType.Lane, ActionSpaceType.Continuous, ActionSpaceType.ActuatorDynamic,
-                        ActionSpaceType.LaneWithContinuousSpeed)
+                        ActionSpaceType.LaneWithContinuousSpeed, ActionSpaceType.Trajectory)
 
 
 @dataclass
@@ -224,7 +224,7 @@ class AgentInterface:
     # ------------------------------------------------------------------ device support
     def validate_for_device(self):
         """Raise for anything the MI355X path does not implement (the Lane,
-        Continuous, ActuatorDynamic and LaneWithContinuousSpeed action spaces and the waypoints /
+        Continuous, ActuatorDynamic, LaneWithContinuousSpeed and Trajectory action spaces and the waypoints /
         neighbourhood / accelerometer / OGM / lidar sensors)."""
         if self.action not in DEVICE_ACTION_SPACES:
             raise NotImplementedError(

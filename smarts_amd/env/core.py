@@ -157,6 +157,34 @@ class BatchCore:
         return out
 
     # ------------------------------------------------------------------ object path
+    def step_actions(self, per_env_actions: Sequence[Dict[str, Any]]):
+        """Per-env ``{agent_id: action}`` dicts -> one device tick (the reference's
+        ``SMARTS.step(agent_actions)``); returns the dict of output tensors."""
+        import torch
+
+        from ..engine import pack_trajectory
+
+        if self.interface.action is not ActionSpaceType.Trajectory:
+            acts = self.encode_actions(per_env_actions)
+            return self.step_dense(torch.from_numpy(acts).to(self.sim.device))
+        # ActionSpaceType.Trajectory: (xs, ys, headings, speeds) per agent (controllers/__init__.py:104-110)
+        slots = self.N + self.num_social
+        packed = np.zeros((self.E, slots, 4, nat.TRAJ_COLS), dtype=np.float64)
+        counts = np.zeros((self.E, slots), dtype=np.int32)
+        for e, agent_actions in enumerate(per_env_actions):
+            assert isinstance(agent_actions, dict) and all(isinstance(k, str) for k in agent_actions), \
+                "Expected Dict[str, any]"  # hiway_env.py:232-234
+            for agent_id, action in agent_actions.items():
+                adapted = self.agent_specs[agent_id].action_adapter(action)
+                i = self.agent_ids.index(agent_id)
+                packed[e, i], counts[e, i] = pack_trajectory(adapted)
+        self._check_alive()
+        if not self._was_reset:
+            raise SMARTSNotSetupError("Must call reset() or setup() before stepping.")
+        out = self.sim.step_trajectory(torch.from_numpy(packed), torch.from_numpy(counts))
+        self.step_count += 1
+        return out
+
     def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
         space = self.interface.action
         lane = space is ActionSpaceType.Lane

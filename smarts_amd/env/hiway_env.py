@@ -127,8 +127,7 @@ class HiWayEnv:
         core = self._core
         import torch
 
-        acts = core.encode_actions([agent_actions])
-        rows = core.host_rows(core.step_dense(torch.from_numpy(acts).to(core.sim.device)))
+        rows = core.host_rows(core.step_actions([agent_actions]))
         observations, rewards, dones, infos = unpack_env(core, rows, 0)
         for done in dones.values():
             self._dones_registered += 1 if done else 0

@@ -83,10 +83,9 @@ class ParallelEnv:
         core = self._core
         if len(actions) != self._num_envs:
             raise ValueError(f"expected {self._num_envs} action dicts, got {len(actions)}")
-        acts = core.encode_actions(actions)
         # the finishing tick's rows are overwritten by the in-launch auto-reset for envs that end;
         # reward / done survive (keep_reward_done), the final observation itself is not kept
-        rows = core.host_rows(core.step_dense(torch.from_numpy(acts).to(core.sim.device)))
+        rows = core.host_rows(core.step_actions(actions))
         obs_b, rew_b, done_b, info_b = [], [], [], []
         for e in range(self._num_envs):
             env_done = bool(rows["env_done"][e])

@@ -552,6 +552,79 @@ def dump_sensors(nets):
     return out
 
 
+def dump_trajectory_pd(rn, net, rng, n):
+    """Reference TrajectoryTrackingController.perform_trajectory_tracking_PD
+    (trajectory_tracking_controller.py:230-331) on mock vehicles; trajectories are the reference's
+    own waypoint paths (positions, headings) with a speed profile, as a Tracker agent would send."""
+    import yaml
+
+    from smarts.core.chassis import AckermannChassis
+    from smarts.core.controllers.trajectory_tracking_controller import (
+        TrajectoryTrackingController,
+        TrajectoryTrackingControllerState,
+    )
+    from smarts.core.coordinates import Heading, Pose
+    from smarts.core.utils.math import fast_quaternion_from_angle
+
+    with open(os.path.join(REF, "smarts", "core", "models", "controller_parameters.yaml")) as f:
+        params = yaml.safe_load(f)["sedan"]["control"]
+    poses = (sample_poses(net, rng, n // 2, lateral=1.0, heading_noise=0.2, far_fraction=0.0)
+             + sample_poses(net, rng, n - n // 2, lateral=0.2, heading_noise=0.03, far_fraction=0.0))
+    TMAX = 11
+    cols = {k: [] for k in ["x", "y", "heading", "speed", "lat_speed", "yaw_z", "n", "traj",
+                            "in_state", "throttle", "brake", "steering", "out_state"]}
+    for (x, y, h) in poses:
+        hd = Heading(h)
+        pose = Pose(position=np.array([x, y, 0.01265]), orientation=fast_quaternion_from_angle(hd), heading_=hd)
+        paths = rn.waypoint_paths(pose, lookahead=int(rng.choice([3, 8, 12, 32])), route=None)
+        if not paths:
+            continue
+        path = paths[int(rng.integers(len(paths)))]
+        npts = len(path)
+        v0 = float(rng.uniform(0.0, 25.0))
+        speeds = [max(0.0, v0 + float(rng.normal(0, 0.5)) * i / max(npts - 1, 1)) for i in range(npts)]
+        trajectory = [[float(w.pos[0]) for w in path], [float(w.pos[1]) for w in path],
+                      [float(w.heading) for w in path], speeds]
+        speed = float(rng.uniform(0.0, 24.0)) if rng.random() < 0.9 else 0.0
+        lat = float(rng.normal(0, 0.3))
+        yawz = float(rng.normal(0, 0.2))
+        chassis = AckermannChassis.__new__(AckermannChassis)
+        chassis.__dict__["longitudinal_lateral_speed"] = (math.sqrt(max(speed * speed - lat * lat, 0.0)), lat)
+        chassis.__dict__["velocity_vectors"] = (np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.0, yawz]))
+        chassis.__dict__["_controller_parameters"] = params
+        captured = {}
+
+        def control(throttle=0, brake=0, steering=0, captured=captured):
+            captured.update(throttle=float(throttle), brake=float(brake), steering=float(steering))
+
+        vehicle = types.SimpleNamespace(chassis=chassis, pose=pose, position=pose.position, heading=hd, speed=speed,
+                                        control=control)
+        st = TrajectoryTrackingControllerState()
+        if rng.random() < 0.8:
+            st.heading_error = float(rng.normal(0, 0.1))
+            st.lateral_error = float(rng.normal(0, 0.3))
+            st.velocity_error = float(rng.normal(0, 1.0))
+            st.integral_velocity_error = float(rng.normal(0, 2.0))
+            st.integral_windup_error = float(rng.normal(0, 0.2))
+            st.steering_state = float(np.clip(rng.normal(0, 0.3), -1, 1))
+            st.throttle_state = float(rng.uniform(-1, 1))
+        fields = ("heading_error", "lateral_error", "velocity_error", "integral_velocity_error", "integral_windup_error",
+                  "steering_state", "throttle_state")
+        in_state = [float(getattr(st, k)) for k in fields]
+        TrajectoryTrackingController.perform_trajectory_tracking_PD(trajectory, vehicle, st, 0.1)
+        # what travels to the device: the first ten points and the last one, plus the true length
+        packed = np.zeros((4, TMAX))
+        for r in range(4):
+            head = trajectory[r][:10]
+            packed[r, :len(head)] = head
+            packed[r, 10] = trajectory[r][-1]
+        for k, v in dict(x=x, y=y, heading=h, speed=speed, lat_speed=lat, yaw_z=yawz, n=npts, traj=packed,
+                         in_state=in_state, out_state=[float(getattr(st, k)) for k in fields],
+                         throttle=captured["throttle"], brake=captured["brake"], steering=captured["steering"]).items():
+            cols[k].append(v)
+    return {k: np.array(v) for k, v in cols.items()}
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -567,7 +640,12 @@ def main():
         nets = {n: load_net(os.path.join(REF, rel)) for n, rel in SCENARIOS.items()}
         np.savez_compressed(os.path.join(OUT, "sensors.npz"), **dump_sensors(nets))
         print("sensor goldens written")
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "trajectory"):
+        net = load_net(os.path.join(REF, SCENARIOS["minicity"]))
+        np.savez_compressed(os.path.join(OUT, "trajectory_pd.npz"),
+                            **dump_trajectory_pd(make_reference_road_network(net), net, np.random.default_rng(21), 260))
+        print("trajectory PD goldens written")
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

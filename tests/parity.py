@@ -209,13 +209,19 @@ def sync_oracle_from_device(ob: "OracleBatch", sim):
             b, c = ag.body, ag.ctrl
             b.x, b.y, b.heading = st[S["X"], g], st[S["Y"], g], st[S["HEADING"], g]
             b.u, b.v, b.yaw_rate_z, b.delta = st[S["U"], g], st[S["V"], g], st[S["R"], g], st[S["DELTA"], g]
-            c.lateral_integral_error = st[S["LAT_INT"], g]
-            c.integral_speed_error = st[S["SPD_INT"], g]
-            c.steering_state = st[S["STEER"], g]
-            c.throttle_state = st[S["THROTTLE"], g]
-            c.speed_error = st[S["SPD_ERR"], g]
-            if flags[g] & nat.F_MCL_SET:
-                c.min_curvature_location = (st[S["MCL_X"], g], st[S["MCL_Y"], g])
+            if hasattr(c, "integral_windup_error"):  # TrajectoryTrackingControllerState (state reuse, smx_vehicle.h)
+                c.lateral_error, c.integral_velocity_error = st[S["LAT_INT"], g], st[S["SPD_INT"], g]
+                c.steering_state, c.throttle_state = st[S["STEER"], g], st[S["THROTTLE"], g]
+                c.velocity_error, c.integral_windup_error = st[S["SPD_ERR"], g], st[S["MCL_X"], g]
+                c.heading_error = st[S["MCL_Y"], g]
+            else:
+                c.lateral_integral_error = st[S["LAT_INT"], g]
+                c.integral_speed_error = st[S["SPD_INT"], g]
+                c.steering_state = st[S["STEER"], g]
+                c.throttle_state = st[S["THROTTLE"], g]
+                c.speed_error = st[S["SPD_ERR"], g]
+                if flags[g] & nat.F_MCL_SET:
+                    c.min_curvature_location = (st[S["MCL_X"], g], st[S["MCL_Y"], g])
             ag.dist_travelled = st[S["DIST"], g]
             if ag.wps_for_distance:
                 w = ag.wps_for_distance[-1]

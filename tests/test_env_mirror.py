@@ -37,8 +37,9 @@ def test_unsupported_interfaces_fail_loudly():
     with pytest.raises(NotImplementedError):
         AgentInterface.from_type(AgentType.Full).validate_for_device()  # rgb / dagm
     with pytest.raises(NotImplementedError):
-        AgentInterface.from_type(AgentType.Tracker).validate_for_device()  # Trajectory action space
-    for t in (AgentType.Standard, AgentType.StandardWithAbsoluteSteering, AgentType.LanerWithSpeed, AgentType.Loner):
+        AgentInterface.from_type(AgentType.MPCTracker).validate_for_device()  # MPC action space
+    for t in (AgentType.Standard, AgentType.StandardWithAbsoluteSteering, AgentType.LanerWithSpeed, AgentType.Loner,
+              AgentType.Tracker):
         AgentInterface.from_type(t).validate_for_device()
     with pytest.raises(NotImplementedError):
         AgentInterface.from_type(AgentType.Laner, rgb=True).validate_for_device()
@@ -77,6 +78,19 @@ def test_float_action_encoding():
     assert env_core.encode_float_action(A.LaneWithContinuousSpeed, (12.0, -1)) == [12.0, -1.0, 0.0]
     with pytest.raises(ValueError):
         env_core.encode_float_action(A.ActuatorDynamic, (0.1, 0.2))
+
+
+def test_trajectory_packing():
+    from smarts_amd.engine import pack_trajectory
+
+    xs = list(range(25))
+    packed, n = pack_trajectory((xs, [2 * x for x in xs], [0.1] * 25, [5.0 + x for x in xs]))
+    assert n == 25 and packed.shape == (4, 11)
+    assert packed[0, :10].tolist() == xs[:10] and packed[0, 10] == 24 and packed[3, 10] == 29.0
+    short, n = pack_trajectory(([1.0, 2.0], [0.0, 0.0], [0.0, 0.0], [3.0, 4.0]))
+    assert n == 2 and short[0, :2].tolist() == [1.0, 2.0] and short[3, 10] == 4.0
+    with pytest.raises(ValueError):
+        pack_trajectory(([1.0], [1.0, 2.0], [0.0], [0.0]))
 
 
 def test_scenario_resolution():

@@ -193,3 +193,26 @@ def test_hiway_env_with_scripted_social_traffic():
         obs, rewards, dones, infos = env.step({"A": "keep_lane", "B": "slow_down"})
     assert set(rewards) == {"A", "B"} and not dones["__all__"]
     env.close()
+
+
+def test_hiway_env_tracker_agent_follows_its_waypoints():
+    """AgentType.Tracker (ActionSpaceType.Trajectory): the agent sends back its first waypoint path
+    with a speed profile, as the reference's examples do."""
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+
+    def act(obs):
+        path = obs.waypoint_paths[0]
+        return ([w.pos[0] for w in path], [w.pos[1] for w in path], [float(w.heading) for w in path], [9.0] * len(path))
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Tracker, max_episode_steps=40),
+                     agent_builder=lambda: Agent.from_function(act))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={"T": spec}, seed=11)
+    agent = spec.build_agent()
+    obs = env.reset()
+    dist = 0.0
+    for _ in range(30):
+        obs, rewards, dones, infos = env.step({"T": agent.act(obs["T"])})
+        dist += rewards["T"]
+        assert not obs["T"].events.off_road
+    assert dist > 15.0 and 6.0 < obs["T"].ego_vehicle_state.speed < 12.0  # settles near the 9 m/s it asks for
+    env.close()

@@ -208,6 +208,51 @@ def test_scripted_social_traffic(name, E, agents, social, T, seed, nets, compile
     sim.close()
 
 
+@pytest.mark.parametrize("name,E,N,T,seed", [("loop", 3, 6, 40, 61), ("minicity", 2, 12, 25, 62)])
+def test_trajectory_action_space(name, E, N, T, seed, nets, compiled_maps):
+    """ActionSpaceType.Trajectory (PD tracking, trajectory_tracking_controller.py:176-331): every
+    agent tracks one of its own waypoint paths with a speed profile; teacher-forced vs the oracle."""
+    import torch
+
+    from oracle import controller as octl
+    from smarts_amd.engine import pack_trajectory
+
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, action_space="Trajectory")
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(seed)
+    for t in range(T):
+        packed = np.zeros((E, N, 4, 11))
+        counts = np.zeros((E, N), dtype=np.int32)
+        oracle_actions = [[([], [], [], []) for _ in range(N)] for _ in range(E)]
+        wp_pos = d["wp_pos"].reshape(E, N, 4, 20, 3)
+        wp_h = d["wp_heading"].reshape(E, N, 4, 20)
+        wp_c = d["wp_count"].reshape(E, N, 5)
+        act = d["active"].reshape(E, N)
+        for e in range(E):
+            for i in range(N):
+                if not act[e, i] or wp_c[e, i, 0] == 0 or (t % 6 == 4 and i == 0):
+                    continue  # gone, nothing to track, or a tick without an action
+                p = int(rng.integers(min(int(wp_c[e, i, 0]), 4)))
+                n = int(rng.choice([3, 7, 10, 11, 20]))
+                n = min(n, int(wp_c[e, i, 1 + p]))
+                v0 = float(rng.choice([0.0, 6.0, 11.0, 16.0, 22.0]))
+                traj = (wp_pos[e, i, p, :n, 0].tolist(), wp_pos[e, i, p, :n, 1].tolist(),
+                        [float(x) for x in wp_h[e, i, p, :n]], [v0 + 0.1 * k for k in range(n)])
+                packed[e, i], counts[e, i] = pack_trajectory(traj)
+                oracle_actions[e][i] = octl.unpack_trajectory(packed[e, i], n)
+        d = _host(sim.step_trajectory(torch.from_numpy(packed), torch.from_numpy(counts)))
+        parts = []
+        for e, env in enumerate(ob.envs):
+            obs, rew, dones = env.step(oracle_actions[e])
+            parts.append(parity.pack(cfg, ob.lane_no, N, obs, rew, dones))
+        o = ob._stack(parts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"trajectory {name} t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 

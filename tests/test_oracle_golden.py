@@ -232,3 +232,30 @@ def test_wrong_way_matches_reference(name, sensor_golden, oracle_maps):
         t = lane.center_pose_heading_at_point((x, y, 0.0))
         assert t == target
         assert bool(np.fabs(rm.heading_relative_to(h, t)) > 0.5 * np.pi) == bool(wrong)
+
+
+def test_trajectory_pd_controller_matches_reference():
+    """TrajectoryTrackingController.perform_trajectory_tracking_PD
+    (trajectory_tracking_controller.py:176-331) run by gen_golden.py on mock vehicles: the oracle
+    restatement, fed the packed form that travels to the device (first ten points + the last one +
+    the true length), reproduces commands and controller state."""
+    g = np.load(os.path.join(GOLDEN, "trajectory_pd.npz"))
+    fields = ("heading_error", "lateral_error", "velocity_error", "integral_velocity_error", "integral_windup_error",
+              "steering_state", "throttle_state")
+    worst = 0.0
+    unsat = 0
+    for i in range(len(g["x"])):
+        veh = types.SimpleNamespace(
+            heading=float(g["heading"][i]), position=np.array([g["x"][i], g["y"][i], 0.01265]), speed=float(g["speed"][i]),
+            angular_velocity=np.array([0.0, 0.0, g["yaw_z"][i]]), longitudinal_lateral_speed=(0.0, float(g["lat_speed"][i])))
+        st = ctl.TrajectoryTrackingControllerState()
+        for k, v in zip(fields, g["in_state"][i]):
+            setattr(st, k, float(v))
+        traj = ctl.unpack_trajectory(g["traj"][i], int(g["n"][i]))
+        thr, brk, steer = ctl.perform_trajectory_tracking_pd(traj, veh, st, 0.1)
+        got = np.array([thr, brk, steer] + [float(getattr(st, k)) for k in fields])
+        ref = np.concatenate([[g["throttle"][i], g["brake"][i], g["steering"][i]], g["out_state"][i]])
+        worst = max(worst, float(np.abs(got - ref).max()))
+        unsat += int(abs(g["steering"][i]) < 1.0)
+    assert worst <= 1e-12, worst
+    assert unsat > 40  # the fixture is not all saturated steering
