@@ -170,7 +170,7 @@ def map_tables_struct(cm: CompiledMap):
 
     keep = []
     t = nat.SmxMapTables()
-    packed = pack_tables(cm)
+    packed = cm.extras.get("packed") or pack_tables(cm)  # scenario_build.load_compiled_map attaches them
     t.n_lanes, t.n_roads = cm.n_lanes, len(cm.road_ids)
     t.n_lanepoints, t.n_shape_pts, t.n_succ = cm.n_lanepoints, len(cm.shape_x), len(packed["succ_rec"])
     for name, dt in _MAP_ARRAYS:

@@ -108,8 +108,7 @@ class BatchCore:
                  auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20),
                  num_social: int = 0):
         from ..engine import BatchedSim, make_spawns
-        from ..map_compiler import compile_map
-        from ..sumo_map import load_net
+        from ..scenario_build import load_compiled_map
 
         self.agent_ids: List[str] = list(agent_specs.keys())
         self.agent_specs = agent_specs
@@ -122,8 +121,7 @@ class BatchCore:
         self.interface: AgentInterface = first
         self.E, self.N, self.dt, self.seed = num_envs, len(self.agent_ids), dt, seed
         self.scenario_dir = resolve_scenario(scenario_dir)
-        self.net = load_net(self.scenario_dir)
-        self.cm = compile_map(self.net)
+        self.cm = load_compiled_map(self.scenario_dir)  # compiled-map cache next to the map (scenario build)
         self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window, num_social)
         self.num_social = num_social
         spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)

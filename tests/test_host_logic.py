@@ -157,3 +157,35 @@ def test_ackermann_formula_reproduces_place_poles():
             assert abs(K[0] - Ka[0]) <= 1e-9 * abs(K[0]) and abs(K[1] - Ka[1]) <= 1e-9 * max(abs(K[1]), 1e-3)
             h, l = ctl.lateral_gains(v, L, M, IZ, C)
             assert l == 3.4 and h == np.clip(Ka[1], 0.02, 0.04) or abs(h - np.clip(Ka[1], 0.02, 0.04)) < 1e-11
+
+
+def test_compiled_map_cache_round_trip(tmp_path):
+    """scenario_build: the `scl scenario build` twin for the map (cli/studio.py:54-84) — cache hit
+    returns identical tables, a changed source map invalidates it."""
+    import dataclasses
+    import shutil
+
+    from smarts_amd.map_compiler import compile_map, pack_tables
+    from smarts_amd.scenario_build import CACHE_NAME, build_scenario, load_compiled_map
+    from smarts_amd.sumo_map import load_net
+
+    src = os.path.join(ROOT, "smarts_amd", "scenarios", "loop")
+    d = tmp_path / "loop"
+    d.mkdir()
+    shutil.copy(os.path.join(src, "map.smxnet.json.gz"), d)
+    first = load_compiled_map(str(d))
+    assert first.extras["from_cache"] is False and (d / CACHE_NAME).exists()
+    again = load_compiled_map(str(d))
+    assert again.extras["from_cache"] is True
+    ref = compile_map(load_net(src))
+    packed = pack_tables(ref)
+    for f in dataclasses.fields(ref):
+        if f.name != "extras":
+            assert np.array_equal(np.asarray(getattr(ref, f.name)), np.asarray(getattr(again, f.name))), f.name
+    for k, v in packed.items():
+        assert np.array_equal(v, again.extras["packed"][k]) and v.dtype == again.extras["packed"][k].dtype
+    # a different source map under the same name: the digest no longer matches
+    shutil.copy(os.path.join(ROOT, "smarts_amd", "scenarios", "intersections", "4lane", "map.smxnet.json.gz"), d)
+    other = load_compiled_map(str(d))
+    assert other.extras["from_cache"] is False and other.n_lanes != ref.n_lanes
+    assert build_scenario(str(d)).endswith(CACHE_NAME)
