@@ -1,21 +1,26 @@
 // smx_kernels.hip — the per-tick kernels of the SMARTS hot path on gfx950, and the C-ABI.
 //
-// A tick = SMARTS._step (smarts.py:236-327) for every environment instance of the shard, as four
-// small kernels on one stream (each stage has its own natural thread mapping; together they
-// stay far below the register pressure of one fused kernel):
+// A tick = SMARTS._step (smarts.py:236-327) for every environment instance of the shard, as a short
+// sequence of kernels on one stream (each stage has its own natural thread mapping; together
+// they stay far below the register pressure of one fused kernel):
 //
-//   k_control    1 thread / vehicle     A controllers (_perform_agent_actions, smarts.py:1233-1263)
+//   k_control   4 lanes / vehicle       A controllers (_perform_agent_actions, smarts.py:1233-1263):
+//                                         the team finds the controller's waypoint path together
 //                                       B physics     (_step_pybullet, smarts.py:923-931)
-//   k_scan       8 lanes  / vehicle     map sweeps at the new pose: nearest lane / road_with_point
-//                                       at centre + 4 corners, 10 nearest lanepoints, path seeds
-//   k_waypoints  4 lanes  / vehicle     D1 waypoint paths (one lane per kept path), LDS-staged
-//                                       so that the dense observation rows leave as full lines;
-//                                       trip meter / reward
-//   k_observe    1 thread / vehicle,    C collisions, D2 neighbours, ego block, accelerometer,
-//                whole envs / workgroup driven path, events, done, teardown, dones["__all__"]
+//   k_scan      8 lanes / vehicle       map sweeps at the new pose: nearest lane / road_with_point
+//                                       at centre + 4 corners, lane heading (wrong way); 10 nearest
+//                                       lanepoints, path seeds
+//   k_sensors   workgroup roles         waypoints role  4 lanes / vehicle: waypoint paths streamed
+//                                         into the dense rows, trip meter / reward
+//                                       observe role    1 lane / vehicle, whole envs / workgroup:
+//                                         collisions, neighbours, ego block, accelerometer, driven
+//                                         path, events, done
+//                                       lidar / OGM roles  1 wavefront / vehicle
+//   k_commit    1 lane / vehicle        new flags (teardown), dones["__all__"], auto-reset respawn
 //
-// followed, for envs whose episode ended under auto_reset (parallel_env.py:303-309), by
-// k_reset + the last three kernels restricted to the re-created vehicles.  Envs are independent
+// followed, for envs whose episode ended under auto_reset (parallel_env.py:303-309), by k_scan /
+// k_sensors / k_commit restricted to the re-created vehicles.  From 32768 vehicles on every role is
+// launched on its own (k_waypoints, k_observe, k_lidar, k_ogm; see enqueue()).  Envs are independent
 // (reference: one process per env, parallel_env.py:96-122): no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 
@@ -32,7 +37,7 @@
 
 #define SMX_BLOCK 64
 #define SMX_COLLISION_LEEWAY 0.05  // chassis.py:75-78
-#define SMX_WP_LANES 4             // lanes of a wavefront that share one vehicle in k_waypoints
+#define SMX_WP_LANES 4             // lanes of a wavefront that share one vehicle (k_control, waypoints role)
 #define SMX_POSE_SCAN_RADIUS 10.0
 
 struct KernelArgs {
@@ -455,7 +460,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
 //          road_with_point at the centre (:498-500) and at the four bounding-box corners
 //          (:502-509; Vehicle.bounding_box vehicle.py:315-332, rotate_around_point math.py:436-444)
 //   seeds: start road / route filter / start lanepoints of waypoint_paths(pose, route)
-//          (sumo_road_network.py:815-882), used by k_waypoints now and by k_control next tick
+//          (sumo_road_network.py:815-882), used by the waypoints role now and by k_control next tick
 // =================================================================================
 // one half of k_scan for one vehicle team (see k_scan)
 __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, const smx_config& c, size_t gid,
@@ -552,7 +557,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
 }
 
 // =================================================================================
-// k_waypoints: waypoint paths (sensors.py:268-275, 972-985) + trip meter (sensors.py:880-947).
+// waypoints role: waypoint paths (sensors.py:268-275, 972-985) + trip meter (sensors.py:880-947).
 // SMX_WP_LANES lanes per vehicle.  Team lane p takes seed lane p and writes its first path straight
 // into the dense rows at the slot it would have if no lower seed lane branches (its provisional
 // number); the team then exchanges the real counts.  Almost always that guess was right and every
@@ -788,7 +793,7 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
 }
 
 // =================================================================================
-// k_observe: the rest of Sensors.observe (sensors.py:238-396) and the events / done logic
+// observe role: the rest of Sensors.observe (sensors.py:238-396) and the events / done logic
 // (sensors.py:443-594), one thread per vehicle, whole envs per workgroup (env-mates' poses in LDS)
 // =================================================================================
 // A vehicle of a freshly reset env: state from the spawn table row of `episode`
@@ -1215,7 +1220,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
 }
 
 // =================================================================================
-// k_ogm: occupancy grid map sensor (OGMSensor, sensors.py:719-758): one wavefront per observing
+// OGM role: occupancy grid map sensor (OGMSensor, sensors.py:719-758): one wavefront per observing
 // vehicle.  The H x W byte tile is built in LDS (lane j rasterises env-mate j's footprint over the
 // few pixels its bounding rectangle touches) and leaves as full 16-byte pieces — the kernel is
 // bound by its own 4 KiB-per-agent output stream.  Pixel rule (substitution for the Panda3D
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
 }
 
 // =================================================================================
-// k_lidar: lidar sensor (LidarSensor sensors.py:797-827, Lidar lidar.py:58-134): one wavefront per
+// lidar role: lidar sensor (LidarSensor sensors.py:797-827, Lidar lidar.py:58-134): one wavefront per
 // observing vehicle, lanes over rays.  Ray i = [origin, origin + base_ray[i]], origin = vehicle
 // position + (0, 0, 1); base rays come from the host (they do not rotate with the vehicle,
 // lidar.py:109-113).  pybullet rayTestBatch is substituted by exact ray / oriented-box and
