@@ -330,6 +330,49 @@ def test_learner_block_is_reward_and_done(auto_reset, compiled_maps):
     sim.close()
 
 
+def test_masked_reset_restarts_only_the_selected_envs(compiled_maps):
+    """smx_reset with an env mask (a ParallelEnv worker resetting its own env, parallel_env.py:294-296):
+    masked envs start their next episode from the next spawn row; the others do not notice."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps("loop")
+    E, N = 4, 6
+    cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0)
+    spawns = make_spawns(cm, E, N, episodes=3, seed=17)
+    sim, twin = BatchedSim(cm, cfg, spawns=spawns), BatchedSim(cm, cfg, spawns=spawns)
+    rng = np.random.default_rng(17)
+    sim.reset(), twin.reset()
+    for t in range(6):
+        acts = torch.from_numpy(_actions(rng, E, N)).cuda()
+        sim.step(acts), twin.step(acts)
+    before = {k: v.clone() for k, v in sim.out.items()}
+    mask = torch.tensor([1, 0, 1, 0], dtype=torch.uint8)
+    out = sim.reset(mask)
+    torch.cuda.synchronize()
+    keep = [1, 3]
+    for k, v in out.items():
+        if k == "learner":
+            continue
+        assert torch.equal(v[keep], before[k][keep]), f"{k}: an unmasked env changed"
+    pos = out["ego_pos"].cpu().numpy().reshape(E, N, 3)
+    for e in (0, 2):
+        assert np.allclose(pos[e, :, :2], spawns[1, e * N:(e + 1) * N, :2])  # second spawn row
+        assert out["active"][e].all() and not out["done"][e].any() and not out["env_done"][e]
+        assert int(sim.env_episode[e]) == 1 and int(sim.env_ticks[e]) == cfg.reset_elapsed_steps()
+    assert int(sim.env_episode[1]) == 0
+    # the unmasked envs keep running exactly like a batch that was never reset
+    for t in range(5):
+        acts = torch.from_numpy(_actions(rng, E, N)).cuda()
+        o1, o2 = sim.step(acts), twin.step(acts)
+    torch.cuda.synchronize()
+    for k in o1:
+        a, b = (o1[k][:, keep], o2[k][:, keep]) if k == "learner" else (o1[k][keep], o2[k][keep])
+        assert torch.equal(a, b), k
+    sim.close(), twin.close()
+
+
 def test_full_size_properties(compiled_maps):
     """BASELINE config sizes through size-independent properties: env independence (a shard of
     the batch computes the same thing as the whole batch), determinism, and invariants of the
