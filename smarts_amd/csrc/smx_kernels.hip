@@ -186,9 +186,11 @@ __device__ __forceinline__ VehState load_vehicle(const KernelArgs& a, size_t gid
 // waypoint of the paths it owns (find_current_lane :367-374) — then the wanted path moves to
 // lane 0 through shuffles and lane 0 runs the control law and the 24 physics substeps.
 // =================================================================================
-__device__ __forceinline__ double team4_get(double v, int src) { return __shfl(v, src, SMX_WP_LANES); }
 
-__global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
+// One instantiation per action space: the Lane kernel does not carry the registers of the others.
+// waves_per_eu(2): at most 256 registers, so that two wavefronts share a SIMD on large batches.
+template <int SPACE>
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
   int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   cs.mcl_y = SF(SMX_S_MCL_Y);
   cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
   // ---- Controllers.perform_action (controllers/__init__.py:61-152)
-  const int space = c.action_space;
+  constexpr int space = SPACE;
   int action = SMX_ACTION_NONE;
   float act0 = 0.f, act1 = 0.f, act2 = 0.f;
   bool has_action;
@@ -243,6 +245,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
     act2 = a.actions_f32[gid * 3 + 2];
     has_action = !(act0 != act0);  // NaN = no action
   }
+  int act_lane = 0;  // the team lane that runs the control law and the physics (uniform in the team)
   ControlOut co;
   // no action this tick: wheel torques do not persist, the steer motor target does
   co.throttle = 0.0;
@@ -402,21 +405,15 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
       int owners = own ? (1 << p0) : 0;
 #pragma unroll
       for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) owners |= __shfl_xor(owners, msk, SMX_WP_LANES);
-      const int src = owners ? (__ffs(owners) - 1) : 0;
-      CtrlPath chosen;
-      chosen.n = __shfl(path.n, src, SMX_WP_LANES);
-#pragma unroll
-      for (int k = 0; k < SMX_CTRL_WPS; ++k) {
-        chosen.x[k] = team4_get(path.x[k], src);
-        chosen.y[k] = team4_get(path.y[k], src);
-        chosen.h[k] = team4_get(path.h[k], src);
-      }
+      // the lane that holds the wanted path carries on alone (control law, physics, state write):
+      // nothing moves between lanes and no second copy of the path is kept in registers
+      act_lane = owners ? (__ffs(owners) - 1) : 0;
       SMX_TSTAMP(tc3);
       SMX_TACC(17, tc2, tc3);
-      if (p0 == 0) {
+      if (p0 == act_lane) {
         // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
-        if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, chosen);
-        co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, chosen);
+        if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, path);
+        co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
       }
       SMX_TSTAMP(tc4);
       SMX_TACC(18, tc3, tc4);
@@ -427,7 +424,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
       co.steering = cs.steer;
     }
   }
-  if (p0 != 0) return;
+  if (p0 != act_lane) return;
   SMX_TSTAMP(tc5);
   SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
   SF(SMX_S_PREV_Y) = s.y;
@@ -531,8 +528,9 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TACC(14, ts0, ts6);
 }
 
+// the back-to-back form only runs on large batches: one more wavefront per SIMD is worth 17 spills
 template <bool SPLIT>
-__global__ void __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 5, 8))) __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -1417,7 +1415,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
 }
 
 // single-role launches: large batches (each role then keeps its own register / LDS footprint and
-// occupancy) and OGM tiles too large to ride along as dynamic LDS of every k_sensors workgroup
+// occupancy; forcing more wavefronts per SIMD onto k_waypoints / k_observe by waves_per_eu cost more
+// in spills than it won: +20 % on loop 4096 x 32) and OGM tiles too large to ride along as dynamic LDS of every k_sensors workgroup
 __global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) { ogm_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
@@ -1836,7 +1835,24 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_COMMIT + 1], stream);
   };
   if (is_step) {
-    hipLaunchKernelGGL(k_control, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+    switch (c.action_space) {
+      case SMX_ACTION_SPACE_LANE:
+        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        break;
+      case SMX_ACTION_SPACE_CONTINUOUS:
+        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_CONTINUOUS>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        break;
+      case SMX_ACTION_SPACE_ACTUATOR_DYNAMIC:
+        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_ACTUATOR_DYNAMIC>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        break;
+      case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
+        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0,
+                           stream, a);
+        break;
+      default:
+        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_TRAJECTORY>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        break;
+    }
     SMX_PHASE_END(SMX_PHASE_CONTROL);
     observation_pass(a, true);
   }
