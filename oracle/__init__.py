@@ -11,16 +11,20 @@ never as part of the shipped path.  ``smarts_amd`` must not import ``oracle``.
 
 Pinning status (see DESIGN.md "Oracle"):
 
-* in-tree arithmetic (math, coordinates, lanepoints, waypoint paths, lane
-  following controller, sensors/events, lidar ray generation): pinned against
-  outputs of the reference's own modules run in the build container
-  (``tests/golden/gen_golden.py`` → ``tests/golden/*.npz|json``) and against
-  the reference's known-answer tests (``tests/test_oracle_kat.py``).
+* in-tree arithmetic — math, coordinates, lanepoints, waypoint paths, nearest
+  lanes, the lane-following and PD trajectory-tracking controllers, the
+  accelerometer / driven-path / trip-meter sensors, the wrong-way test, lidar
+  ray generation, ``lane_ttc`` / ``FormatObs``: pinned against outputs of the
+  reference's own modules run in the build container
+  (``tests/golden/gen_golden.py`` → ``tests/golden/*.npz``) and against the
+  reference's known-answer tests (``tests/test_oracle_kat.py``).
 * third-party arithmetic that is absent from the reference tree (pybullet
   dynamics/contacts/ray casts, Panda3D OGM raster, sumolib+rtree map queries):
   restated from the reference's call sites; map queries are pinned by the
   ``test_map.py`` known answers; **vehicle pose trajectories are parity
   unpinned** (the reference holds no golden poses and pybullet cannot run
   here) — the planar model in ``oracle/dynamics.py`` is a documented
-  substitution.
+  substitution.  Likewise **unpinned**: the OGM raster beyond the reference's
+  +-2 px check, lidar hits (ray / box instead of Bullet), and the scripted
+  social-traffic model that stands in for SUMO (``oracle/sim.py::SocialBody``).
 """
