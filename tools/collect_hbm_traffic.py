@@ -20,6 +20,14 @@ import os
 from collections import defaultdict
 
 
+def kernel_name(raw):
+    """'void k_control<0>(KernelArgs)' -> 'k_control': templated kernels are reported with their signature."""
+    name = raw.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    return name.split("<")[0]
+
+
 def read_counters(directory, counter):
     per_kernel = defaultdict(float)
     dispatches = defaultdict(int)
@@ -31,7 +39,7 @@ def read_counters(directory, counter):
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0]
+                name = kernel_name(row["Kernel_Name"])
                 per_kernel[name] += float(row["Counter_Value"])
                 dispatches[name] += 1
     return per_kernel, dispatches

@@ -4,12 +4,19 @@
 import csv, glob, os, sys
 from collections import defaultdict
 
+def kernel_name(raw):
+    name = raw.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    return name.split("<")[0]
+
+
 tot = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
 for d in sys.argv[1:]:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"].split("(")[0]
+                k = kernel_name(row["Kernel_Name"])
                 if not k.startswith("k_"):
                     continue
                 if int(row["Grid_Size"]) < 4096:   # reset-pass stubs at tiny grids are not interesting
