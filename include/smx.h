@@ -95,6 +95,7 @@ enum {
   SMX_ACTION_SPACE_TRAJECTORY = 4 /* smx_step_trajectory: PD tracking (trajectory_tracking_controller.py:176-331) */
 };
 
+#define SMX_MAX_ALIVE_LISTS 4
 typedef struct smx_config {
   int32_t num_envs;          /* E: environment instances in this shard            */
   int32_t num_vehicles;      /* N: vehicle slots per instance (<= 64)             */
@@ -126,6 +127,15 @@ typedef struct smx_config {
    * arclength offset, SMX_S_SPD_INT = lanes crossed. */
   int32_t num_social;
   double social_speed_factor;
+  /* DoneCriteria.agents_alive (agent_interface.py:155-176, sensors.py:404-441): an agent is done
+   * when fewer agents are left in its env than asked.  Counts are taken over the agents registered
+   * at the start of the tick (agent_manager ids).  0 = not set; alive_list_mask[k] bit i = agent
+   * slot i belongs to list k (agents_list), alive_list_min[k] = minimum_agents_alive_in_list. */
+  int32_t alive_min_ego;
+  int32_t alive_min_total;
+  int32_t alive_lists;          /* number of lists used, <= SMX_MAX_ALIVE_LISTS */
+  int32_t alive_list_min[4];
+  uint64_t alive_list_mask[4];
 } smx_config;
 
 /* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */

@@ -49,6 +49,9 @@ class AgentConfig:
     done_not_moving: bool = False
     not_moving_time: float = 60
     not_moving_distance: float = 1
+    alive_min_ego: Optional[int] = None  # DoneCriteria.agents_alive (agent_interface.py:155-176)
+    alive_min_total: Optional[int] = None
+    alive_lists: tuple = ()  # ((agent slots), minimum alive) pairs
     action_space: str = "Lane"  # Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
     ogm: Optional[tuple] = None  # (width, height, resolution) — OGM (agent_interface.py:42-51)
     lidar_rays: Optional[np.ndarray] = None  # base rays [R, 3] (sensors_extra.base_rays)
@@ -436,8 +439,10 @@ class OracleEnv:
         is_not_moving = self._not_moving(ag)
         reached_max = cfg.max_episode_steps is not None and ag.steps >= cfg.max_episode_steps
         is_off_route, is_wrong_way = self._off_route_and_wrong_way(b)
+        agents_alive_done = self._agents_alive_done(cfg)
         done = (
-            (is_off_road and cfg.done_off_road)
+            agents_alive_done
+            or (is_off_road and cfg.done_off_road)
             or reached_goal
             or reached_max
             or (is_on_shoulder and cfg.done_on_shoulder)
@@ -455,9 +460,22 @@ class OracleEnv:
             on_shoulder=is_on_shoulder,
             wrong_way=is_wrong_way,
             not_moving=is_not_moving,
-            agents_alive_done=False,
+            agents_alive_done=agents_alive_done,
         )
         return bool(done), events
+
+    def _agents_alive_done(self, cfg):
+        """sensors.py:404-441: ``agent_manager.agent_ids`` holds the agents not yet torn down, i.e.
+        alive at the start of this tick (teardown follows the observations, smarts.py:314)."""
+        ids = {i for i, a in enumerate(self.agents) if a.alive}
+        if cfg.alive_min_ego and len(ids) < cfg.alive_min_ego:
+            return True
+        if cfg.alive_min_total and len(ids) < cfg.alive_min_total:
+            return True
+        for slots, minimum in cfg.alive_lists:
+            if [1 if i in ids else 0 for i in slots].count(1) < minimum:
+                return True
+        return False
 
     def _not_moving(self, ag):
         """sensors.py:511-525, 855-877."""

@@ -52,6 +52,8 @@ class SmxConfig(C.Structure):
         ("not_moving_distance", _f64), ("auto_reset", _i32), ("reset_elapsed_steps", _i32),
         ("ogm_width", _i32), ("ogm_height", _i32), ("ogm_resolution", _f64), ("lidar_rays", _i32),
         ("lidar_max_distance", _f64), ("action_space", _i32), ("num_social", _i32), ("social_speed_factor", _f64),
+        ("alive_min_ego", _i32), ("alive_min_total", _i32), ("alive_lists", _i32), ("alive_list_min", _i32 * 4),
+        ("alive_list_mask", C.c_uint64 * 4),
     ]
 
 

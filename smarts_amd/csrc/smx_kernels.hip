@@ -1123,12 +1123,26 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     ev[SMX_EV_NOT_MOVING] = is_not_moving ? 1 : 0;
     ev[SMX_EV_REACHED_GOAL] = reached_goal ? 1 : 0;
     ev[SMX_EV_REACHED_MAX_EPISODE_STEPS] = reached_max ? 1 : 0;
-    ev[SMX_EV_AGENTS_ALIVE_DONE] = 0;
+    // ---- DoneCriteria.agents_alive (sensors.py:404-441): agents registered at the start of the tick
+    bool agents_alive_done = false;
+    if (c.alive_min_ego > 0 || c.alive_min_total > 0 || c.alive_lists > 0) {
+      unsigned long long alive_mask = 0ull;
+      const int n_agents = n_veh - c.num_social;
+      for (int j = 0; j < n_agents; ++j)
+        if (env_pose[j].alive) alive_mask |= 1ull << j;
+      const int n_alive = __popcll(alive_mask);
+      // no social *agents* exist on this path, so every registered agent is an ego agent
+      if (c.alive_min_ego > 0 && n_alive < c.alive_min_ego) agents_alive_done = true;
+      if (c.alive_min_total > 0 && n_alive < c.alive_min_total) agents_alive_done = true;
+      for (int k = 0; k < c.alive_lists && k < SMX_MAX_ALIVE_LISTS; ++k)
+        if (__popcll(alive_mask & c.alive_list_mask[k]) < c.alive_list_min[k]) agents_alive_done = true;
+    }
+    ev[SMX_EV_AGENTS_ALIVE_DONE] = agents_alive_done ? 1 : 0;
     const uint32_t dc = c.done_criteria;
     done = (is_off_road && (dc & SMX_DONE_OFF_ROAD)) || reached_goal || reached_max ||
            (is_on_shoulder && (dc & SMX_DONE_ON_SHOULDER)) || (collided && (dc & SMX_DONE_COLLISION)) ||
            (is_not_moving && (dc & SMX_DONE_NOT_MOVING)) || (is_off_route && (dc & SMX_DONE_OFF_ROUTE)) ||
-           (is_wrong_way && (dc & SMX_DONE_WRONG_WAY));
+           (is_wrong_way && (dc & SMX_DONE_WRONG_WAY)) || agents_alive_done;
     if (first) done = false;  // sensors.py:465: `not sim.resetting and (...)`: reset observations never end an agent
 
     // ---- teardown (smarts.py:314, 329-363)
@@ -1570,6 +1584,8 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
+  if (c.alive_lists < 0 || c.alive_lists > SMX_MAX_ALIVE_LISTS || c.alive_min_ego < 0 || c.alive_min_total < 0)
+    return fail(h, SMX_ERR_INVALID, "agents_alive: at most 4 lists, non-negative minima");
   if (c.num_social < 0 || c.num_social >= c.num_vehicles)
     return fail(h, SMX_ERR_INVALID, "num_social must leave at least one agent slot");
   if (c.num_social > 0 && !(c.social_speed_factor >= 0.0))

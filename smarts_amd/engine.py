@@ -51,6 +51,11 @@ class SimConfig:
     ogm_height: int = 256
     ogm_resolution: float = 50 / 256
     lidar: Optional[SensorParams] = None  # agent_interface.py:132-135
+    # DoneCriteria.agents_alive (agent_interface.py:155-176): minima (None = unset) and up to four
+    # (agent slots, minimum alive) lists
+    alive_min_ego: Optional[int] = None
+    alive_min_total: Optional[int] = None
+    alive_lists: Sequence = ()
     num_social: int = 0  # scripted social vehicles: the last num_social slots of every env (include/smx.h)
     social_speed_factor: float = 0.8
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
@@ -224,6 +229,17 @@ class BatchedSim:
                              f"(supported: {sorted(nat.ACTION_SPACES)})")
         c.action_space = nat.ACTION_SPACES[cfg.action_space]
         c.num_social, c.social_speed_factor = int(cfg.num_social), float(cfg.social_speed_factor)
+        c.alive_min_ego, c.alive_min_total = int(cfg.alive_min_ego or 0), int(cfg.alive_min_total or 0)
+        if len(cfg.alive_lists) > 4:
+            raise ValueError("DoneCriteria.agents_alive: at most four agent lists on the accelerated path")
+        c.alive_lists = len(cfg.alive_lists)
+        for k, (slots, minimum) in enumerate(cfg.alive_lists):
+            mask = 0
+            for i in slots:
+                if not 0 <= int(i) < N - cfg.num_social:
+                    raise ValueError(f"agents_alive list {k}: slot {i} is not an agent slot")
+                mask |= 1 << int(i)
+            c.alive_list_mask[k], c.alive_list_min[k] = mask, int(minimum)
         if cfg.ogm:
             c.ogm_width, c.ogm_height, c.ogm_resolution = cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution
         if cfg.lidar is not None:

@@ -235,5 +235,6 @@ class AgentInterface:
                 raise NotImplementedError(f"AgentInterface.{name} is not on the accelerated path")
         if self.vehicle_type != "sedan":
             raise NotImplementedError("only the sedan chassis is modelled")
-        if self.done_criteria.agents_alive is not None:
-            raise NotImplementedError("DoneCriteria.agents_alive is not on the accelerated path")
+        alive = self.done_criteria.agents_alive
+        if alive is not None and alive.agent_lists_alive and len(alive.agent_lists_alive) > 4:
+            raise NotImplementedError("DoneCriteria.agents_alive: at most four agent lists on the accelerated path")

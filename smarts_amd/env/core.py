@@ -72,7 +72,8 @@ def encode_float_action(space: ActionSpaceType, action: Any):
 
 
 def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: int, dt: float, auto_reset: bool,
-                              waypoint_window: Tuple[int, int] = (4, 20), num_social: int = 0):
+                              waypoint_window: Tuple[int, int] = (4, 20), num_social: int = 0,
+                              agent_ids: Optional[Sequence[str]] = None):
     """AgentInterface -> SimConfig (one interface for every agent, as FormatObs also requires,
     format_obs.py:207-210)."""
     from ..engine import SimConfig
@@ -90,6 +91,16 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
         not_moving_time=evc.not_moving_time, not_moving_distance=evc.not_moving_distance, auto_reset=auto_reset,
         action_space=itf.action.name,
     )
+    alive = dc.agents_alive
+    if alive is not None:
+        kw.update(alive_min_ego=alive.minimum_ego_agents_alive, alive_min_total=alive.minimum_total_agents_alive)
+        lists = []
+        for lst in alive.agent_lists_alive or ():
+            if agent_ids is None:
+                raise ValueError("agents_alive lists need the agent ids")
+            # ids that are not agents of this env are never alive (sensors.py:432-435)
+            lists.append(([agent_ids.index(a) for a in lst.agents_list if a in agent_ids], lst.minimum_agents_alive_in_list))
+        kw["alive_lists"] = tuple(lists)
     if itf.waypoints:
         # the dense rows keep the StdObs window (format_obs.py:42) unless the lookahead is shorter
         kw["wp_paths"] = waypoint_window[0]
@@ -122,7 +133,8 @@ class BatchCore:
         self.E, self.N, self.dt, self.seed = num_envs, len(self.agent_ids), dt, seed
         self.scenario_dir = resolve_scenario(scenario_dir)
         self.cm = load_compiled_map(self.scenario_dir)  # compiled-map cache next to the map (scenario build)
-        self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window, num_social)
+        self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window, num_social,
+                                             self.agent_ids)
         self.num_social = num_social
         spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)
         self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed, social_spawns=where)

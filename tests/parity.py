@@ -23,6 +23,8 @@ def oracle_config(cfg):
         not_moving_time=cfg.not_moving_time,
         not_moving_distance=cfg.not_moving_distance,
         action_space=cfg.action_space,
+        alive_min_ego=cfg.alive_min_ego, alive_min_total=cfg.alive_min_total,
+        alive_lists=tuple((tuple(s_), m) for s_, m in cfg.alive_lists),
         ogm=(cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution) if cfg.ogm else None,
         lidar_rays=oracle_lidar_rays(cfg.lidar) if cfg.lidar is not None else None,
     )

@@ -109,6 +109,12 @@ def test_sim_config_from_interface():
     assert (cfg.num_envs, cfg.num_vehicles, cfg.wp_lookahead, cfg.wp_paths, cfg.wp_len) == (3, 5, 32, 4, 20)
     assert cfg.neighbors and cfg.nb_radius == 30.0 and cfg.ogm and cfg.ogm_width == 64 and cfg.lidar is None
     assert cfg.done_on_shoulder and not cfg.done_collision and cfg.max_episode_steps == 11 and cfg.auto_reset
+    from smarts_amd.env.agent_interface import AgentsAliveDoneCriteria, AgentsListAlive
+
+    alive = AgentInterface.from_type(AgentType.Laner, done_criteria=DoneCriteria(agents_alive=AgentsAliveDoneCriteria(
+        minimum_ego_agents_alive=2, agent_lists_alive=[AgentsListAlive(agents_list=["b", "zz", "c"], minimum_agents_alive_in_list=1)])))
+    ca = env_core.sim_config_from_interface(alive, 1, 3, 0.1, False, agent_ids=["a", "b", "c"])
+    assert ca.alive_min_ego == 2 and ca.alive_min_total is None and ca.alive_lists == (([1, 2], 1),)
     short = env_core.sim_config_from_interface(AgentInterface.from_type(AgentType.Laner, waypoints=Waypoints(8)), 1, 1, 0.1, False)
     assert short.wp_len == 9
 

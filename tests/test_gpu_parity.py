@@ -133,6 +133,9 @@ VARIANTS = {
     "all_done_criteria": dict(done_on_shoulder=True, done_wrong_way=True, done_not_moving=True, not_moving_time=0.5,
                               not_moving_distance=1.0, done_collision=False, max_episode_steps=15),
     "half_timestep": dict(dt=0.05),
+    # DoneCriteria.agents_alive: the fleet thins out by max_episode_steps on a stagger-free clock, so
+    # force early exits with collisions off and a shoulder criterion; the rest follow by the rule
+    "agents_alive": dict(done_on_shoulder=True, alive_min_ego="N", alive_lists=(((0, 1, 2), 2),), max_episode_steps=14),
     "no_neighbours": dict(neighbors=False),
 }
 
@@ -149,6 +152,8 @@ def test_config_variants(variant, name, E, N, nets, compiled_maps):
     cm = compiled_maps(name)
     kw = dict(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0)
     kw.update(VARIANTS[variant])
+    if kw.get("alive_min_ego") == "N":
+        kw["alive_min_ego"] = N  # the first agent to leave takes the others with it one tick later
     cfg = SimConfig(**kw)
     spawns = make_spawns(cm, E, N, episodes=2, seed=77)
     sim = BatchedSim(cm, cfg, spawns=spawns)
@@ -157,6 +162,7 @@ def test_config_variants(variant, name, E, N, nets, compiled_maps):
     assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
     rng = np.random.default_rng(77)
     T = 8 if N == 64 else 18
+    seen_alive_done = 0
     for t in range(T):
         acts = _actions(rng, E, N)
         if variant == "all_done_criteria":
@@ -164,7 +170,10 @@ def test_config_variants(variant, name, E, N, nets, compiled_maps):
         d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
         bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{variant} {name} t{t} ")
         assert bad == [], "\n".join(bad[:8])
+        seen_alive_done += int(d["events"][:, 8].sum())
         parity.sync_oracle_from_device(ob, sim)
+    if variant == "agents_alive":
+        assert seen_alive_done > 0  # the criterion fired
     sim.close()
 
 
