@@ -131,6 +131,7 @@ typedef struct smx_config {
    * when fewer agents are left in its env than asked.  Counts are taken over the agents registered
    * at the start of the tick (agent_manager ids).  0 = not set; alive_list_mask[k] bit i = agent
    * slot i belongs to list k (agents_list), alive_list_min[k] = minimum_agents_alive_in_list. */
+  int32_t via_max;           /* near-via rows kept per agent (<= 32); 0 = via sensor off */
   int32_t alive_min_ego;
   int32_t alive_min_total;
   int32_t alive_lists;          /* number of lists used, <= SMX_MAX_ALIVE_LISTS */
@@ -250,6 +251,7 @@ enum {
   SMX_FI_LANE = 0, SMX_FI_FLAGS, SMX_FI_TRIP_START, SMX_FI_OBS_START,
   SMX_FI_TRIP_HAS_WP, /* trip meter holds a waypoint (TripMeterSensor._wps_for_distance non-empty); persists across ticks */
   SMX_FI_FLAGS_NEXT,  /* the flags word after this tick's observation, applied by the commit kernel */
+  SMX_FI_VIA_CONSUMED, /* bit v: via v of the agent's list was hit in this episode (ViaSensor._consumed_via_points) */
   SMX_FACT_I_COUNT
 };
 enum { SMX_FF_LANE_DIST = 0, SMX_FF_LANE_HEADING /* lane heading at the nearest centre-line point */, SMX_FACT_F_COUNT };
@@ -287,6 +289,12 @@ typedef struct smx_outputs {
   uint8_t* done;         /* [E*N]                                             */
   uint8_t* active;       /* [E*N] 1 while the agent has a vehicle after this tick */
   uint8_t* env_done;     /* [E]   dones["__all__"] (hiway_env.py:258-261)     */
+  /* via sensor (if smx_set_vias gave any): the near vias (within the 40 m lane acquisition range,
+   * vehicle.py:553-557) as indices into the agent's list, nearest first, -1 padded; bit v of
+   * via_hit = via v was hit this tick */
+  int8_t* via_near;      /* [E*N][via_max]                                    */
+  uint8_t* via_near_count; /* [E*N]                                           */
+  int32_t* via_hit;      /* [E*N]                                             */
   /* optional learner-facing block [2][E*N] float32: row 0 = reward, row 1 = done, rewritten whole
    * every tick (absent agents read 0) — what a multi-GPU job gathers per tick;
    * the caller may alternate buffers between ticks.  NULL if unused. */
@@ -318,6 +326,17 @@ typedef struct smx_outputs {
 /* ---- entry points ---- */
 int smx_create(const smx_config* cfg, int device, smx_handle* out);
 int smx_load_map(smx_handle h, const smx_map_tables* map);
+/* Via points of the agents' missions (plan.py:180-188; ViaSensor sensors.py:1090-1149).  One list per
+ * agent slot, shared by every env: vias[slot_off[s] .. slot_off[s+1]) belong to slot s (at most 32
+ * each).  Host pointers; the library keeps a device copy.  n = 0 clears. */
+typedef struct smx_via {
+  double x, y;            /* Via.position */
+  double hit_distance;
+  double required_speed;
+  int32_t lane;           /* Via.lane_id as a lane table index */
+  int32_t pad;
+} smx_via;
+int smx_set_vias(smx_handle h, const smx_via* vias_host, int32_t n, const int32_t* slot_off_host);
 /* Base ray directions (device, [lidar_rays][3]); reference lidar.py:89-113 */
 int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t n_rays);
 /* Re-initialise the envs whose mask byte is non-zero (NULL = all) from the spawn

@@ -207,7 +207,7 @@ class _Social:
 class OracleEnv:
     """One SMARTS instance with N ego agents (and optional scripted social vehicles) on one map."""
 
-    def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8):
+    def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8, vias=None):
         """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre) for the agents followed
         by the social vehicles; ``social``: (lane id, arclength offset) per social vehicle."""
         self.road_map = road_map
@@ -223,6 +223,10 @@ class OracleEnv:
         spawns = np.asarray(spawns, dtype=np.float64)
         n_agents = len(spawns) - len(social)
         self.agents = [_Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(spawns[:n_agents], configs)]
+        # per agent: the mission's vias as dicts(lane_id, position, hit_distance, required_speed, ...)
+        self.vias = vias if vias is not None else [[] for _ in self.agents]
+        for ag in self.agents:
+            ag.consumed_vias = set()
         self.social = [
             _Social(SocialBody(*spawns[n_agents + k], road_map.lane_by_id(lane_id), off, n_agents + k, social_speed_factor))
             for k, (lane_id, off) in enumerate(social)
@@ -384,6 +388,8 @@ class OracleEnv:
             o["ogm"] = sx.ogm(b, [ob for _, ob in alive_states], *cfg.ogm)
         if cfg.lidar_rays is not None:  # sensors.py:297-301
             o["lidar"] = sx.lidar(b, [ob for j, ob in alive_states if j != i], cfg.lidar_rays)
+        if self.vias[i]:
+            o["vias"] = self._via_sensor(ag, self.vias[i])
         done, events = self._is_done_with_events(ag)
         o["events"] = events
         o["dt"] = self.dt
@@ -463,6 +469,31 @@ class OracleEnv:
             agents_alive_done=agents_alive_done,
         )
         return bool(done), events
+
+    def _via_sensor(self, ag, vias, acquisition_range=40, speed_accuracy=1.5):
+        """ViaSensor.__call__ (sensors.py:1103-1146; range / tolerance from vehicle.py:553-557):
+        (indices of the near vias, nearest first; indices hit this tick)."""
+        b = ag.body
+        pos = np.array(b.position[:2])
+        near, hit = [], []
+        for k, via in enumerate(vias):
+            lane = self.road_map.lane_by_id(via["lane_id"])
+            centre = np.array(lane.from_lane_coord(lane.offset_along_lane(tuple(pos)))[:2])  # center_at_point
+            delta = centre - pos
+            if np.dot(delta, delta) > acquisition_range ** 2:
+                continue
+            near.append(k)
+            dv = np.array(via["position"]) - pos
+            if (np.dot(dv, dv) <= via["hit_distance"] ** 2 and k not in ag.consumed_vias
+                    and np.isclose(b.speed, via["required_speed"], atol=speed_accuracy)):
+                ag.consumed_vias.add(k)
+                hit.append(k)
+
+        def sq(k):
+            d = pos - np.array(vias[k]["position"])  # squared_dist(point.position, vehicle_position)
+            return np.dot(d, d)
+
+        return sorted(near, key=sq), hit
 
     def _agents_alive_done(self, cfg):
         """sensors.py:404-441: ``agent_manager.agent_ids`` holds the agents not yet torn down, i.e.

@@ -32,7 +32,7 @@ STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT
 S = {name: i for i, name in enumerate(STATE_FIELDS)}
 S_COUNT = len(STATE_FIELDS)
 F_ALIVE, F_MCL_SET, F_TRIP_HAS_WP, F_HIST_SHIFT, F_FIRST, F_SOCIAL = 1, 2, 4, 3, 32, 64
-FACT_I_COUNT, FACT_F_COUNT = 6, 2
+FACT_I_COUNT, FACT_F_COUNT = 7, 2
 DRIVEN_PATH_LEN = 500
 SEED_COUNT = 9
 EGO = dict(HEADING=0, SPEED=1, STEERING=2, YAW_RATE=3, LIN_VEL=4, ANG_VEL=7, LIN_ACC=10, ANG_ACC=13, LIN_JERK=16,
@@ -51,7 +51,7 @@ class SmxConfig(C.Structure):
         ("nb_max", _i32), ("nb_radius", _f64), ("max_episode_steps", _i32), ("not_moving_time", _f64),
         ("not_moving_distance", _f64), ("auto_reset", _i32), ("reset_elapsed_steps", _i32),
         ("ogm_width", _i32), ("ogm_height", _i32), ("ogm_resolution", _f64), ("lidar_rays", _i32),
-        ("lidar_max_distance", _f64), ("action_space", _i32), ("num_social", _i32), ("social_speed_factor", _f64),
+        ("lidar_max_distance", _f64), ("action_space", _i32), ("num_social", _i32), ("social_speed_factor", _f64), ("via_max", _i32),
         ("alive_min_ego", _i32), ("alive_min_total", _i32), ("alive_lists", _i32), ("alive_list_min", _i32 * 4),
         ("alive_list_mask", C.c_uint64 * 4),
     ]
@@ -78,6 +78,10 @@ class SmxState(C.Structure):
                 ("env_reset_pending", _p)]
 
 
+class SmxVia(C.Structure):
+    _fields_ = [("x", _f64), ("y", _f64), ("hit_distance", _f64), ("required_speed", _f64), ("lane", _i32), ("pad", _i32)]
+
+
 class SmxSpawns(C.Structure):
     _fields_ = [("episodes", _i32), ("pose", _p), ("social", _p)]
 
@@ -88,6 +92,9 @@ OUTPUT_FIELDS = [
     "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
     "ogm", "lidar_hit", "lidar_point",
 ]
+OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("learner"), "via_hit")
+OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_hit"), "via_near_count")
+OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_near_count"), "via_near")
 
 
 class SmxOutputs(C.Structure):
@@ -95,7 +102,7 @@ class SmxOutputs(C.Structure):
 
 
 EXPORTS = [
-    "smx_create", "smx_load_map", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
+    "smx_create", "smx_load_map", "smx_set_vias", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
 ]
 
@@ -146,6 +153,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_read_step_ms.restype = C.c_int
     lib.smx_step_continuous.argtypes = [h, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
     lib.smx_step_continuous.restype = C.c_int
+    lib.smx_set_vias.argtypes = [h, C.POINTER(SmxVia), _i32, C.POINTER(_i32)]
+    lib.smx_set_vias.restype = C.c_int
     lib.smx_step_trajectory.argtypes = [h, _p, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
     lib.smx_step_trajectory.restype = C.c_int
     lib.smx_read_phase_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]

@@ -52,6 +52,8 @@ struct KernelArgs {
   const int32_t* traj_n;     // ... true lengths, 0 = no action
   const uint8_t* env_mask;  // k_reset: explicit mask (NULL = use env_reset_pending / all)
   const double* lidar_rays;
+  const smx_via* vias;          // device copy of smx_set_vias
+  const int32_t* via_slot_off;  // [num_vehicles + 1]
   int first_only;           // restrict to vehicles carrying SMX_F_FIRST (reset observations)
   int keep_reward_done;     // auto-reset: the terminal step's reward / done / env_done stay
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
@@ -864,6 +866,11 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
     }
     o.nb_count[gid] = 0;
   }
+  if (c.via_max > 0 && o.via_near) {
+    for (int k = 0; k < c.via_max; ++k) o.via_near[gid * (size_t)c.via_max + k] = -1;
+    o.via_near_count[gid] = 0;
+    o.via_hit[gid] = 0;
+  }
   if ((c.sensors & SMX_SENSOR_OGM) && o.ogm) {
     const size_t n = (size_t)c.ogm_width * c.ogm_height;
     for (size_t k = 0; k < n; ++k) o.ogm[gid * n + k] = 0;
@@ -1090,6 +1097,53 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
       SF(SMX_S_PATH_SUM) = sum;
       double elapsed = (double)env_ticks * c.dt;
       if (!(elapsed < c.not_moving_time)) is_not_moving = sum < c.not_moving_distance;
+    }
+
+    // ---- via sensor (ViaSensor.__call__, sensors.py:1103-1146; acquisition range 40 m and speed
+    //      tolerance 1.5 m/s from vehicle.py:553-557)
+    if (c.via_max > 0 && a.vias != nullptr) {
+      const int v_a = a.via_slot_off[slot], v_b = a.via_slot_off[slot + 1];
+      int32_t* consumed_p = a.st.facts_i32 + (size_t)SMX_FI_VIA_CONSUMED * total + gid;
+      unsigned consumed = first ? 0u : (unsigned)*consumed_p;
+      int hit = 0, cnt = 0;
+      int8_t* near = o.via_near + gid * (size_t)c.via_max;
+      for (int v = v_a; v < v_b; ++v) {
+        const smx_via via = a.vias[v];
+        double qx, qy;
+        lane_center_at_point(m, via.lane, px, py, qx, qy);
+        const double lx = qx - px, ly = qy - py;
+        if (lx * lx + ly * ly > 40.0 * 40.0) continue;
+        const double dx = via.x - px, dy = via.y - py;
+        const double d2 = dx * dx + dy * dy;
+        // sorted(near_points, key=squared distance): stable insertion keeps list order among equals
+        // (the kept rows live in the output itself; a row's distance is recomputed from the table)
+        int pos = cnt < c.via_max ? cnt : c.via_max;
+        while (pos > 0) {
+          const smx_via prev = a.vias[v_a + near[pos - 1]];
+          const double ex = prev.x - px, ey = prev.y - py;
+          if (ex * ex + ey * ey > d2)
+            --pos;
+          else
+            break;
+        }
+        if (pos < c.via_max) {
+          const int last = (cnt < c.via_max ? cnt : c.via_max - 1);
+          for (int k = last; k > pos; --k) near[k] = near[k - 1];
+          near[pos] = (int8_t)(v - v_a);
+        }
+        ++cnt;
+        const int bit = 1 << (v - v_a);
+        // np.isclose(speed, required_speed, atol=1.5) with the default rtol = 1e-5
+        const bool speed_ok = fabs(speed - via.required_speed) <= 1.5 + 1e-5 * fabs(via.required_speed);
+        if (d2 <= via.hit_distance * via.hit_distance && !(consumed & bit) && speed_ok) {
+          consumed |= bit;
+          hit |= bit;
+        }
+      }
+      for (int k = (cnt < c.via_max ? cnt : c.via_max); k < c.via_max; ++k) near[k] = -1;
+      o.via_near_count[gid] = (uint8_t)(cnt > 255 ? 255 : cnt);
+      o.via_hit[gid] = hit;
+      *consumed_p = (int32_t)consumed;
     }
 
     // ---- events + done (sensors.py:443-489)
@@ -1493,6 +1547,9 @@ struct smx_handle_s {
   void* map_blob;  // one device allocation holding every table
   size_t map_bytes;
   const double* lidar_rays;
+  smx_via* vias_dev;
+  int32_t* via_off_dev;
+  int32_t n_vias;
   double heading_gain_pos, lateral_gain_pos;
   int debug_skip;
   bool timing;
@@ -1572,6 +1629,9 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->ev_used = 0;
   h->phase_timing = false;
   h->ph_used = 0;
+  h->vias_dev = nullptr;
+  h->via_off_dev = nullptr;
+  h->n_vias = 0;
   {
     const char* dbg = getenv("SMX_DEBUG_SKIP");
     h->debug_skip = dbg ? atoi(dbg) : 0;
@@ -1584,6 +1644,7 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
+  if (c.via_max < 0 || c.via_max > 32) return fail(h, SMX_ERR_INVALID, "via_max must be in 0..32");
   if (c.alive_lists < 0 || c.alive_lists > SMX_MAX_ALIVE_LISTS || c.alive_min_ego < 0 || c.alive_min_total < 0)
     return fail(h, SMX_ERR_INVALID, "agents_alive: at most 4 lists, non-negative minima");
   if (c.num_social < 0 || c.num_social >= c.num_vehicles)
@@ -1708,6 +1769,36 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   return SMX_OK;
 }
 
+extern "C" int smx_set_vias(smx_handle h, const smx_via* vias_host, int32_t n, const int32_t* slot_off_host) {
+  if (!h) return SMX_ERR_INVALID;
+  if (n < 0 || (n > 0 && (!vias_host || !slot_off_host))) return fail(h, SMX_ERR_INVALID, "smx_set_vias: null table");
+  if (n > 0 && h->cfg.via_max <= 0) return fail(h, SMX_ERR_INVALID, "smx_set_vias: cfg.via_max is 0");
+  if (n > 0 && !h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_set_vias needs the map (lane indices are checked)");
+  const int nv = h->cfg.num_vehicles;
+  if (n > 0) {
+    if (slot_off_host[0] != 0 || slot_off_host[nv] != n) return fail(h, SMX_ERR_INVALID, "smx_set_vias: slot offsets");
+    for (int s = 0; s < nv; ++s)
+      if (slot_off_host[s + 1] < slot_off_host[s] || slot_off_host[s + 1] - slot_off_host[s] > 32)
+        return fail(h, SMX_ERR_INVALID, "smx_set_vias: at most 32 vias per agent, offsets ascending");
+    for (int i = 0; i < n; ++i)
+      if (vias_host[i].lane < 0 || vias_host[i].lane >= h->map.n_lanes)
+        return fail(h, SMX_ERR_INVALID, "smx_set_vias: lane index out of range");
+  }
+  SMX_HIP(hipSetDevice(h->device));
+  if (h->vias_dev) (void)hipFree(h->vias_dev);
+  if (h->via_off_dev) (void)hipFree(h->via_off_dev);
+  h->vias_dev = nullptr;
+  h->via_off_dev = nullptr;
+  h->n_vias = 0;
+  if (n == 0) return SMX_OK;
+  SMX_HIP(hipMalloc(&h->vias_dev, (size_t)n * sizeof(smx_via)));
+  SMX_HIP(hipMalloc(&h->via_off_dev, (size_t)(nv + 1) * sizeof(int32_t)));
+  SMX_HIP(hipMemcpy(h->vias_dev, vias_host, (size_t)n * sizeof(smx_via), hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy(h->via_off_dev, slot_off_host, (size_t)(nv + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->n_vias = n;
+  return SMX_OK;
+}
+
 extern "C" int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t n_rays) {
   if (!h) return SMX_ERR_INVALID;
   if (n_rays != h->cfg.lidar_rays) return fail(h, SMX_ERR_INVALID, "n_rays != cfg.lidar_rays");
@@ -1732,6 +1823,8 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (!o->nb_pos || !o->nb_box || !o->nb_heading || !o->nb_speed ||
                                              !o->nb_lane_index || !o->nb_lane_id || !o->nb_slot || !o->nb_count))
     return fail(h, SMX_ERR_INVALID, "neighbourhood sensor enabled but an output buffer is null");
+  if (c.via_max > 0 && h->n_vias > 0 && (!o->via_near || !o->via_near_count || !o->via_hit))
+    return fail(h, SMX_ERR_INVALID, "vias are set but a via output buffer is null");
   if ((c.sensors & SMX_SENSOR_OGM) && !o->ogm) return fail(h, SMX_ERR_INVALID, "ogm sensor enabled but out.ogm is null");
   if ((c.sensors & SMX_SENSOR_LIDAR) && (!o->lidar_hit || !o->lidar_point))
     return fail(h, SMX_ERR_INVALID, "lidar sensor enabled but an output buffer is null");
@@ -1773,6 +1866,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.traj_n = traj_n;
   a.env_mask = mask;
   a.lidar_rays = h->lidar_rays;
+  a.vias = h->n_vias > 0 ? h->vias_dev : nullptr;
+  a.via_slot_off = h->via_off_dev;
   a.first_only = 0;
   a.keep_reward_done = 0;
   a.reset_all = 0;
@@ -1977,6 +2072,8 @@ extern "C" const char* smx_last_error(smx_handle h) { return h ? h->err.c_str() 
 extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
+  if (h->vias_dev) (void)hipFree(h->vias_dev);
+  if (h->via_off_dev) (void)hipFree(h->via_off_dev);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ph_pool) (void)hipEventDestroy(e);
   delete h;

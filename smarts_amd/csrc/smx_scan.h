@@ -439,3 +439,54 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   const double qz = sin(half), qw = cos(half);
   return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
 }
+
+
+// ---------------------------------------------------------------------------------
+// Lane.center_at_point (road_map.py:357-360): from_lane_coord(offset_along_lane(point)) — the point of
+// the lane's centre line closest to (px, py).  One-lane form (the via sensor asks it for a handful of
+// lanes per agent); same arithmetic as team_lane_heading_at_point's first half.
+// ---------------------------------------------------------------------------------
+__device__ inline void lane_center_at_point(const MapDev& m, int lane, double px, double py, double& cx, double& cy) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  double offset = -1.0;
+  bool on_vertex = false;
+  for (int v = v0; v < v1 && !on_vertex; ++v) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.x == px && a.y == py) {
+      on_vertex = true;
+      offset = a.cum;
+    }
+  }
+  if (!on_vertex) {
+    double min_dist = SMX_INF;
+    for (int v = v0; v + 1 < v1; ++v) {
+      const smx_shape_rec a = m.shape_rec[v], b = m.shape_rec[v + 1];
+      const double gx = fmax(fmax(fmin(a.x, b.x) - px, px - fmax(a.x, b.x)), 0.0);
+      const double gy = fmax(fmax(fmin(a.y, b.y) - py, py - fmax(a.y, b.y)), 0.0);
+      const double keep = min_dist + 1e-6;
+      if (gx * gx + gy * gy > keep * keep) continue;
+      const double d = a.len;
+      const double u = ((px - a.x) * (b.x - a.x)) + ((py - a.y) * (b.y - a.y));
+      const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+      double fx, fy;
+      position_at_offset(a.x, a.y, b.x, b.y, d, poff, fx, fy);
+      const double dist = euclid(px, py, fx, fy);
+      if (dist < min_dist) {
+        min_dist = dist;
+        offset = poff + a.cum;
+      }
+    }
+  }
+  // position_at_shape_offset (utils/math.py:319-331)
+  for (int v = v0; v + 1 < v1; ++v) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.cum + a.len > offset) {
+      const smx_shape_rec b = m.shape_rec[v + 1];
+      position_at_offset(a.x, a.y, b.x, b.y, a.len, offset - a.cum, cx, cy);
+      return;
+    }
+  }
+  const smx_shape_rec z = m.shape_rec[v1 - 1];
+  cx = z.x;
+  cy = z.y;
+}

@@ -56,6 +56,7 @@ class SimConfig:
     alive_min_ego: Optional[int] = None
     alive_min_total: Optional[int] = None
     alive_lists: Sequence = ()
+    via_max: int = 0  # near-via rows per agent (the via sensor runs when BatchedSim gets vias)
     num_social: int = 0  # scripted social vehicles: the last num_social slots of every env (include/smx.h)
     social_speed_factor: float = 0.8
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
@@ -202,7 +203,9 @@ class BatchedSim:
     """One shard of environment instances resident on one GPU."""
 
     def __init__(self, cm: CompiledMap, cfg: SimConfig, device: str = "cuda:0", spawns: Optional[np.ndarray] = None,
-                 spawn_episodes: int = 2, seed: int = 42, first_env: int = 0, social_spawns: Optional[np.ndarray] = None):
+                 spawn_episodes: int = 2, seed: int = 42, first_env: int = 0, social_spawns: Optional[np.ndarray] = None,
+                 vias: Optional[Sequence[Sequence]] = None):
+        """``vias``: per agent slot, a list of ``vias.ResolvedVia`` (the missions' via points)."""
         self.lib = nat.load_library()
         if not torch.cuda.is_available():
             raise nat.NativeLibraryError("no ROCm device visible: the smarts_amd hot path runs on the GPU only")
@@ -229,6 +232,10 @@ class BatchedSim:
                              f"(supported: {sorted(nat.ACTION_SPACES)})")
         c.action_space = nat.ACTION_SPACES[cfg.action_space]
         c.num_social, c.social_speed_factor = int(cfg.num_social), float(cfg.social_speed_factor)
+        self.vias = [list(v) for v in vias] if vias is not None else None
+        if self.vias is not None and cfg.via_max <= 0:
+            raise ValueError("vias need SimConfig(via_max > 0)")
+        c.via_max = int(cfg.via_max)
         c.alive_min_ego, c.alive_min_total = int(cfg.alive_min_ego or 0), int(cfg.alive_min_total or 0)
         if len(cfg.alive_lists) > 4:
             raise ValueError("DoneCriteria.agents_alive: at most four agent lists on the accelerated path")
@@ -251,6 +258,16 @@ class BatchedSim:
         tables, keep = map_tables_struct(cm)
         nat.check(self.lib, self.handle, self.lib.smx_load_map(self.handle, C.byref(tables)), "smx_load_map")
         del keep
+        if self.vias is not None:
+            if len(self.vias) != N:
+                raise ValueError("vias: one list per vehicle slot")
+            flat = [v for lst in self.vias for v in lst]
+            recs = (nat.SmxVia * max(len(flat), 1))()
+            for i, v in enumerate(flat):
+                recs[i].x, recs[i].y = v.position
+                recs[i].hit_distance, recs[i].required_speed, recs[i].lane = v.hit_distance, v.required_speed, v.lane
+            offs = (C.c_int32 * (N + 1))(*np.concatenate([[0], np.cumsum([len(lst) for lst in self.vias])]).astype(int).tolist())
+            nat.check(self.lib, self.handle, self.lib.smx_set_vias(self.handle, recs, len(flat), offs), "smx_set_vias")
         if cfg.lidar is not None:
             self.lidar_rays = torch.from_numpy(base_rays(cfg.lidar)).to(dev)
             rc = self.lib.smx_set_lidar_rays(self.handle, self.lidar_rays.data_ptr(), int(self.lidar_rays.shape[0]))
@@ -333,6 +350,10 @@ class BatchedSim:
             o["nb_lane_id"] = z((E, N, K), torch.int16)
             o["nb_slot"] = z((E, N, K), torch.int8)
             o["nb_count"] = z((E, N), torch.uint8)
+        if cfg.via_max > 0:
+            o["via_near"] = torch.full((E, N, cfg.via_max), -1, dtype=torch.int8, device=dev)
+            o["via_near_count"] = z((E, N), torch.uint8)
+            o["via_hit"] = z((E, N), torch.int32)
         if cfg.ogm:
             o["ogm"] = z((E, N, cfg.ogm_height, cfg.ogm_width), torch.uint8)
         if cfg.lidar is not None:

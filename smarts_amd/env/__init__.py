@@ -10,6 +10,7 @@ from .format_obs import FormatObs, StdObs  # noqa: F401
 from .hiway_env import HiWayEnv  # noqa: F401
 from .observations import (  # noqa: F401
     Collision, Dimensions, EgoVehicleObservation, Events, GridMapMetadata, Heading, Observation, OccupancyGridMap,
-    VehicleObservation, Vias, Waypoint,
+    VehicleObservation, ViaPoint, Vias, Waypoint,
 )
+from ..vias import Via  # noqa: F401
 from .parallel_env import ParallelEnv  # noqa: F401

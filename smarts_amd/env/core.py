@@ -117,7 +117,7 @@ class BatchCore:
 
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
                  auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20),
-                 num_social: int = 0):
+                 num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None):
         from ..engine import BatchedSim, make_spawns
         from ..scenario_build import load_compiled_map
 
@@ -137,13 +137,24 @@ class BatchCore:
                                              self.agent_ids)
         self.num_social = num_social
         spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)
-        self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed, social_spawns=where)
+        # mission vias (sstudio Via per agent id) -> resolved lists per vehicle slot
+        self.vias = None
+        if vias:
+            from ..vias import resolve_vias
+
+            unknown = set(vias) - set(self.agent_ids)
+            if unknown:
+                raise ValueError(f"vias for unknown agents: {sorted(unknown)}")
+            self.vias = [resolve_vias(self.cm, vias.get(a, ())) for a in self.agent_ids] + [[] for _ in range(num_social)]
+            self.cfg.via_max = 8
+        self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed, social_spawns=where,
+                              vias=self.vias)
         road_ids = [self.cm.road_ids[r] for r in self.cm.lane_road]
         vehicle_names = self.agent_ids + [f"social-{k}" for k in range(num_social)]
         self.builder = ObservationBuilder(
             self.cm.lane_ids, road_ids, vehicle_names, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
             accelerometer=self.cfg.accelerometer, ogm=first.ogm or None,
-            lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt)
+            lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias)
         self._was_reset = False
         self._destroyed = False
         self.step_count = np.zeros(num_envs, dtype=np.int64)

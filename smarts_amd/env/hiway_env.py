@@ -44,6 +44,7 @@ class HiWayEnv:
         device: str = "cuda:0",
         waypoint_window: Tuple[int, int] = (4, 20),
         num_social: int = 0,
+        vias: Optional[Dict[str, Sequence]] = None,
     ):
         self._log = logging.getLogger(self.__class__.__name__)
         if not headless or envision_record_data_replay_path or envision_endpoint:
@@ -66,6 +67,9 @@ class HiWayEnv:
         self._waypoint_window = waypoint_window
         # scripted social traffic (the accelerated path's stand-in for the scenario's SUMO flows)
         self._num_social = int(num_social)
+        # mission via points per agent id (smarts_amd.vias.Via = sstudio's Via); the reference reads them
+        # from the scenario's missions, which this path does not parse
+        self._vias = dict(vias) if vias else None
         self._dones_registered = 0
         self._core: Optional[BatchCore] = None
         self._seed = seed
@@ -96,7 +100,7 @@ class HiWayEnv:
         """What must agree for envs to share one device batch (ParallelEnv)."""
         specs = self._agent_specs
         return (self._scenario, tuple(specs.keys()), tuple(repr(s.interface) for s in specs.values()), self._dt,
-                self._waypoint_window, self._num_social)
+                self._waypoint_window, self._num_social, repr(self._vias))
 
     def seed(self, seed: int) -> int:
         """hiway_env.py:204-214.  Takes effect at the next ``reset`` that (re)builds the spawn table."""
@@ -115,7 +119,7 @@ class HiWayEnv:
         if self._core is None:
             self._core = BatchCore(self._scenario, self._agent_specs, num_envs=1, dt=self._dt, seed=self._seed,
                                    auto_reset=False, device=self._device, waypoint_window=self._waypoint_window,
-                                   num_social=self._num_social)
+                                   num_social=self._num_social, vias=self._vias)
         return self._core
 
     def step(self, agent_actions) -> Tuple[Dict[str, Observation], Dict[str, float], Dict[str, bool], Dict[str, Any]]:

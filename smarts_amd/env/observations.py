@@ -159,6 +159,16 @@ class OccupancyGridMap(NamedTuple):
     data: np.ndarray
 
 
+@dataclass
+class ViaPoint:
+    """sensors.py:145-157."""
+
+    position: Tuple[float, float]
+    lane_index: float
+    road_id: str
+    required_speed: float
+
+
 @dataclass(frozen=True)
 class Vias:
     """sensors.py:165-172 (missions here carry no vias)."""
@@ -202,12 +212,13 @@ class ObservationBuilder:
 
     def __init__(self, lane_ids: Sequence[str], lane_road_ids: Sequence[str], agent_ids: Sequence[str], *,
                  waypoints: bool, neighbors: bool, accelerometer: bool, ogm=None, lidar_rays: Optional[np.ndarray] = None,
-                 dt: float = 0.1):
+                 dt: float = 0.1, vias=None):
         self.lane_ids = list(lane_ids)
         self.lane_road_ids = list(lane_road_ids)
         self.agent_ids = list(agent_ids)
         self.waypoints, self.neighbors, self.accelerometer = waypoints, neighbors, accelerometer
         self.ogm, self.lidar_rays, self.dt = ogm, lidar_rays, dt
+        self.vias = vias  # per vehicle slot: resolved mission vias (smarts_amd.vias.ResolvedVia)
 
     def vehicle_id(self, slot: int) -> str:
         # Vehicle.build_agent_vehicle (vehicle.py:371-372) names agent vehicles after their agent;
@@ -292,8 +303,20 @@ class ObservationBuilder:
             pts = [np.array(p, dtype=np.float64) for p in rows["lidar_point"][slot]]
             rays = [(origin.copy(), origin + d) for d in self.lidar_rays]  # lidar.py:109-113
             lidar = (pts, hits, rays)
+        via_data = Vias(near_via_points=[], hit_via_points=[])
+        if self.vias is not None and self.vias[slot] and "via_near" in rows:
+            mine = self.vias[slot]
+
+            def point(k):
+                v = mine[k]
+                return ViaPoint(position=tuple(v.position), lane_index=v.lane_index, road_id=v.road_id,
+                                required_speed=v.required_speed)
+
+            near = [point(int(k)) for k in rows["via_near"][slot] if k >= 0]
+            hit = [point(k) for k in range(len(mine)) if int(rows["via_hit"][slot]) >> k & 1]
+            via_data = Vias(near_via_points=near, hit_via_points=hit)
         return Observation(
             dt=self.dt, step_count=step_count, elapsed_sim_time=elapsed_sim_time, events=events, ego_vehicle_state=ego,
             neighborhood_vehicle_states=neighbors, waypoint_paths=paths, distance_travelled=float(rows["dist"][slot]),
             lidar_point_cloud=lidar, drivable_area_grid_map=None, occupancy_grid_map=ogm, top_down_rgb=None,
-            road_waypoints=None, via_data=Vias(near_via_points=[], hit_via_points=[]))
+            road_waypoints=None, via_data=via_data)

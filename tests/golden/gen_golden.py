@@ -625,6 +625,55 @@ def dump_trajectory_pd(rn, net, rng, n):
     return {k: np.array(v) for k, v in cols.items()}
 
 
+def dump_via_sensor(net):
+    """Reference ViaSensor (sensors.py:1090-1149) on scenarios/intersections/4lane with the via points of
+    that scenario's EndlessMission (scenario.py:24-73), resolved as Scenario.to_scenario_via does
+    (scenario.py:652-676), for a vehicle driven through them at various speeds."""
+    from unittest.mock import Mock
+
+    from smarts.core.coordinates import RefLinePoint
+    from smarts.core.plan import Via as PlanVia
+    from smarts.core.sensors import ViaSensor
+
+    rn = make_reference_road_network(net)
+    spec = [("edge-south-SN", 1, 30, 4), ("edge-west-EW", 0, 20, 8), ("edge-west-EW", 1, 50, 2), ("edge-west-EW", 0, 55, 5),
+            ("edge-west-EW", 1, 60, 2), ("edge-west-EW", 0, 65, 2), ("edge-west-EW", 1, 70, 2)]
+    vias = []
+    for road_id, lane_index, off, speed in spec:
+        lane = rn.road_by_id(road_id).lane_at_index(lane_index)
+        pos = lane.from_lane_coord(RefLinePoint(off))
+        vias.append(PlanVia(lane_id=lane.lane_id, road_id=road_id, lane_index=lane_index, position=tuple(pos[:2]),
+                            hit_distance=lane.width_at_offset(off) / 2, required_speed=speed))
+    plan = Mock()
+    plan.mission.via = tuple(vias)
+    plan.road_map = rn
+    vehicle = Mock()
+    sensor = ViaSensor(vehicle, plan, lane_acquisition_range=40, speed_accuracy=1.5)
+    # drive up edge-south-SN lane 1, then along edge-west-EW weaving between its two lanes
+    track = []
+    lane = rn.road_by_id("edge-south-SN").lane_at_index(1)
+    for off in np.arange(5.0, 55.0, 1.7):
+        p = lane.from_lane_coord(RefLinePoint(float(off)))
+        track.append((float(p[0]), float(p[1]), 4.3 if off < 33 else 9.0))
+    for k, off in enumerate(np.arange(2.0, 95.0, 1.3)):
+        lane = rn.road_by_id("edge-west-EW").lane_at_index(int(k // 9) % 2)
+        p = lane.from_lane_coord(RefLinePoint(float(off)))
+        track.append((float(p[0]), float(p[1]), [8.2, 2.5, 5.9, 1.2][int(k // 12) % 4]))
+    near_out, hit_out = [], []
+    for (x, y, speed) in track:
+        vehicle.position = np.array([x, y, 0.0])
+        vehicle.speed = speed
+        near, hit = sensor()
+        idx = {(v.position, v.lane_index, v.required_speed): i for i, v in enumerate(vias)}
+        near_out.append([idx[(p.position, p.lane_index, p.required_speed)] for p in near] + [-1] * (len(vias) - len(near)))
+        hit_out.append([1 if any(h.position == v.position for h in hit) else 0 for v in vias])
+    return dict(
+        via_lane_ids=np.array([v.lane_id for v in vias]), via_pos=np.array([v.position for v in vias]),
+        via_hit_distance=np.array([v.hit_distance for v in vias]), via_speed=np.array([float(v.required_speed) for v in vias]),
+        via_spec=np.array([[s_[1], s_[2], s_[3]] for s_ in spec], dtype=np.float64), via_roads=np.array([s_[0] for s_ in spec]),
+        track=np.array(track), near=np.array(near_out), hit=np.array(hit_out))
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -645,7 +694,10 @@ def main():
         np.savez_compressed(os.path.join(OUT, "trajectory_pd.npz"),
                             **dump_trajectory_pd(make_reference_road_network(net), net, np.random.default_rng(21), 260))
         print("trajectory PD goldens written")
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "vias"):
+        np.savez_compressed(os.path.join(OUT, "via_sensor.npz"), **dump_via_sensor(load_net(os.path.join(REF, SCENARIOS["4lane"]))))
+        print("via sensor goldens written")
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

@@ -57,6 +57,9 @@ def empty_dense(cfg, n):
             nb_lane_id=np.full((n, K), -1, np.int16), nb_slot=np.full((n, K), -1, np.int8),
             nb_count=np.zeros(n, np.uint8),
         )
+    if cfg.via_max > 0:
+        d.update(via_near=np.full((n, cfg.via_max), -1, np.int8), via_near_count=np.zeros(n, np.uint8),
+                 via_hit=np.zeros(n, np.int32))
     if cfg.ogm:
         d["ogm"] = np.zeros((n, cfg.ogm_height, cfg.ogm_width), np.uint8)
     if cfg.lidar is not None:
@@ -124,6 +127,11 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
                 d["nb_lane_index"][i, k] = nv["lane_index"] if nv["lane_index"] is not None else -1
                 d["nb_lane_id"][i, k] = lane_no[nv["lane_id"]] if nv["lane_id"] is not None else -1
                 d["nb_slot"][i, k] = nv["slot"]
+        if cfg.via_max > 0 and "vias" in o:
+            near, hit = o["vias"]
+            d["via_near_count"][i] = min(len(near), 255)
+            d["via_near"][i, :min(len(near), cfg.via_max)] = near[:cfg.via_max]
+            d["via_hit"][i] = sum(1 << k for k in hit)
         if cfg.ogm:
             d["ogm"][i] = o["ogm"]
         if cfg.lidar is not None:
@@ -134,7 +142,7 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
 
 
 INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
-            "nb_lane_id", "nb_slot", "nb_count", "ogm", "lidar_hit"]
+            "nb_lane_id", "nb_slot", "nb_count", "ogm", "lidar_hit", "via_near", "via_near_count", "via_hit"]
 
 
 def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
@@ -164,7 +172,7 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
 class OracleBatch:
     """E independent oracle envs driven with the same spawns/actions as the device."""
 
-    def __init__(self, net, cm, cfg, spawns_ep0, social_ep0=None):
+    def __init__(self, net, cm, cfg, spawns_ep0, social_ep0=None, vias=None):
         self.cfg = cfg
         self.road_map = ORoadNetwork(net, lanepoint_spacing=cm.lanepoint_spacing)
         self.lane_no = {lid: i for i, lid in enumerate(cm.lane_ids)}
@@ -177,8 +185,12 @@ class OracleBatch:
             social = []
             if K:
                 social = [(cm.lane_ids[int(l)], float(off)) for l, off in social_ep0[rows][self.N - K:]]
+            ovias = None
+            if vias is not None:
+                ovias = [[dict(lane_id=v.lane_id, position=v.position, hit_distance=v.hit_distance,
+                               required_speed=v.required_speed) for v in lst] for lst in vias[:self.N - K]]
             self.envs.append(OracleEnv(self.road_map, spawns_ep0[rows], [ocfg] * (self.N - K), dt=cfg.dt, social=social,
-                                       social_speed_factor=cfg.social_speed_factor))
+                                       social_speed_factor=cfg.social_speed_factor, vias=ovias))
 
     def _stack(self, parts):
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}

@@ -216,3 +216,21 @@ def test_hiway_env_tracker_agent_follows_its_waypoints():
         assert not obs["T"].events.off_road
     assert dist > 15.0 and 6.0 < obs["T"].ego_vehicle_state.speed < 12.0  # settles near the 9 m/s it asks for
     env.close()
+
+
+def test_hiway_env_reports_mission_vias():
+    """Observation.via_data (sensors.py:165-172): near vias sorted by distance, hits when passed at speed."""
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv, Via
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Laner, max_episode_steps=60),
+                     agent_builder=lambda: Agent.from_function(lambda _: "keep_lane"))
+    vias = [Via("edge-south-SN", 1, 30, 13, hit_distance=4.0), Via("edge-south-SN", 0, 45, 13, hit_distance=4.0),
+            Via("edge-west-EW", 0, 20, 8)]
+    env = HiWayEnv(scenarios=["scenarios/intersections/4lane"], agent_specs={"A": spec, "B": spec}, seed=5,
+                   vias={"A": vias})
+    obs = env.reset()
+    assert obs["B"].via_data.near_via_points == [] and len(obs["A"].via_data.near_via_points) >= 1
+    pos = obs["A"].ego_vehicle_state.position[:2]
+    d = [np.hypot(p.position[0] - pos[0], p.position[1] - pos[1]) for p in obs["A"].via_data.near_via_points]
+    assert d == sorted(d) and obs["A"].via_data.near_via_points[0].road_id.startswith("edge-")
+    env.close()

@@ -259,3 +259,30 @@ def test_trajectory_pd_controller_matches_reference():
         unsat += int(abs(g["steering"][i]) < 1.0)
     assert worst <= 1e-12, worst
     assert unsat > 40  # the fixture is not all saturated steering
+
+
+def test_via_sensor_matches_reference(oracle_maps, compiled_maps):
+    """ViaSensor (sensors.py:1090-1149) and Scenario.to_scenario_via (scenario.py:652-676) run by
+    gen_golden.py on scenarios/intersections/4lane: the product's via resolution and the oracle's sensor."""
+    from oracle.sim import OracleEnv
+    from smarts_amd.vias import Via, resolve_vias
+
+    g = np.load(os.path.join(GOLDEN, "via_sensor.npz"))
+    cm = compiled_maps("4lane")
+    vias = resolve_vias(cm, [Via(str(r), int(s[0]), float(s[1]), float(s[2])) for r, s in zip(g["via_roads"], g["via_spec"])])
+    assert [v.lane_id for v in vias] == [str(x) for x in g["via_lane_ids"]]
+    assert np.array_equal(np.array([v.position for v in vias]), g["via_pos"])
+    assert np.array_equal(np.array([v.hit_distance for v in vias]), g["via_hit_distance"])
+    rmap = oracle_maps("4lane")
+    env = types.SimpleNamespace(road_map=rmap)
+    ag = types.SimpleNamespace(consumed_vias=set(), body=None)
+    ovias = [dict(lane_id=v.lane_id, position=v.position, hit_distance=v.hit_distance, required_speed=v.required_speed)
+             for v in vias]
+    hits = 0
+    for t, (x, y, speed) in enumerate(g["track"]):
+        ag.body = types.SimpleNamespace(position=np.array([x, y, 0.0]), speed=float(speed))
+        near, hit = OracleEnv._via_sensor(env, ag, ovias)
+        assert near == [int(k) for k in g["near"][t] if k >= 0], t
+        assert [1 if k in hit else 0 for k in range(len(vias))] == g["hit"][t].tolist(), t
+        hits += len(hit)
+    assert hits == int(g["hit"].sum()) and hits >= 2
