@@ -609,7 +609,7 @@ __device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
   }
 }
 
-__device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int block) {
+__device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t gid) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
   int* knots = knot_scratch + threadIdx.x;
   const smx_config& c = a.cfg;
@@ -617,7 +617,6 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
   const smx_outputs& o = a.out;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
-  const size_t gid = ((size_t)block * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
@@ -790,6 +789,10 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
     if (o.learner) o.learner[gid] = (float)(dist - last_dist);
   }
   *trip_has_wp_p = trip_has_wp ? 1 : 0;  // the flags word itself is not written here (the observe role owns it)
+}
+
+__device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int block) {
+  waypoints_for(a, ((size_t)block * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES);
 }
 
 // =================================================================================
@@ -1231,7 +1234,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
 // the reset pass that follows builds the first observations of the restarted envs.
 // One thread per vehicle, whole envs per workgroup.
 // =================================================================================
-__global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
+__device__ __forceinline__ void commit_role(const KernelArgs& a, const int block) {
   __shared__ int env_new_done[SMX_BLOCK];
   __shared__ int env_respawn[SMX_BLOCK];
   __shared__ int env_first_alive[SMX_BLOCK];
@@ -1242,7 +1245,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
   const int local = threadIdx.x;
   const int env_local = local / n_veh;
   const int slot = local - env_local * n_veh;
-  const int env = blockIdx.x * epb + env_local;
+  const int env = block * epb + env_local;
   const bool valid = (env_local < epb) && (env < c.num_envs);
   const size_t total = (size_t)c.num_envs * n_veh;
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
@@ -1284,6 +1287,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) {
     a.st.env_ticks[env] = c.reset_elapsed_steps;
   }
 }
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) { commit_role(a, (int)blockIdx.x); }
 
 // =================================================================================
 // OGM role: occupancy grid map sensor (OGMSensor, sensors.py:719-758): one wavefront per observing
@@ -1480,6 +1485,59 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
   } else {
     ogm_role(a, b - a.wp_blocks - a.obs_blocks - a.lidar_blocks);
   }
+}
+
+// =================================================================================
+// k_first: the reset pass (first observations of re-created vehicles) as ONE launch.  A workgroup
+// owns the envs of one observe-role group and runs scan -> sensors -> commit for their new vehicles
+// itself, phase after phase; results pass between phases through global memory behind a fence and a
+// barrier.  Almost always no env of the group has restarted and the workgroup leaves at once, so an
+// auto-reset tick pays for one empty launch instead of three.  (OGM tiles need dynamic LDS and keep
+// their own launch.)
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_first(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const int n_veh = c.num_vehicles;
+  const int epb = SMX_BLOCK / n_veh;
+  const int block = (int)blockIdx.x;
+  const size_t total = (size_t)c.num_envs * n_veh;
+  const size_t g0 = (size_t)block * epb * n_veh;
+  const size_t g1 = min(total, g0 + (size_t)epb * n_veh);
+  int mine_first = 0;
+  if (g0 + threadIdx.x < g1) {
+    const int f = a.st.flags[g0 + threadIdx.x];
+    mine_first = (f & SMX_F_ALIVE) && (f & SMX_F_FIRST);
+  }
+  if (!__syncthreads_or(mine_first)) return;
+  // ---- scan: SMX_TEAM lanes per vehicle, both halves
+  for (size_t base = g0; base < g1; base += SMX_BLOCK / SMX_TEAM) {
+    const size_t gid = base + threadIdx.x / SMX_TEAM;
+    if (gid < g1) {
+      const int flags = a.st.flags[gid];
+      if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) {
+        scan_role(a, m, c, gid, total, team_rank(), flags, 0);
+        scan_role(a, m, c, gid, total, team_rank(), flags, 1);
+      }
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  // ---- sensors
+  for (size_t base = g0; base < g1; base += SMX_BLOCK / SMX_WP_LANES) {
+    const size_t gid = base + threadIdx.x / SMX_WP_LANES;
+    if (gid < g1) waypoints_for(a, gid);
+  }
+  observe_role(a, block);
+  if (c.sensors & SMX_SENSOR_LIDAR)
+    for (size_t gid = g0; gid < g1; ++gid) {
+      lidar_role(a, (int)gid);
+      __syncthreads();  // the role's LDS block is reused by the next vehicle
+    }
+  __threadfence();
+  __syncthreads();
+  // ---- commit
+  commit_role(a, block);
 }
 
 // single-role launches: large batches (each role then keeps its own register / LDS footprint and
@@ -1977,7 +2035,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_reset, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, r);
       hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     }
-    observation_pass(r, false);
+    if (ogm_bytes) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, r);
+    hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
   if (phased) {
