@@ -50,6 +50,9 @@ def init_process_group(backend: Optional[str] = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            # one process per GPU: bind the rank to its device before the first collective
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
