@@ -137,7 +137,7 @@ def main():
     if rank == 0:
         build.build()
     if world > 1:
-        dist.barrier()
+        sharding.barrier()
 
     from smarts_amd import lidar as lidar_mod
 
@@ -171,7 +171,7 @@ def main():
     gather.finish()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        sharding.barrier()
     sim.set_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -179,7 +179,7 @@ def main():
     gather.finish()  # every tick's gather has landed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        sharding.barrier()
     elapsed = time.perf_counter() - t0
     sim.set_timing(False)
     kernel_ms = sim.read_step_ms()
@@ -277,7 +277,7 @@ def main():
         print(json.dumps(line))
     sim.close()
     if world > 1:
-        dist.barrier()
+        sharding.barrier()
         dist.destroy_process_group()
 
 

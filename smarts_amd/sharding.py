@@ -57,6 +57,16 @@ def init_process_group(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
+def barrier():
+    """dist.barrier that names the rank's device under NCCL (avoids the device guess)."""
+    if not dist.is_initialized():
+        return
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 class RewardDoneGather:
     """Per-tick gather of the learner-facing block: reward (f32) and done (u8) of every agent of
     every shard, packed as one f32 tensor ``[2, E_shard * N]`` so that it is ONE small collective
