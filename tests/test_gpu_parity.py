@@ -320,7 +320,8 @@ def test_free_running_rollout_pose_bar(nets, compiled_maps):
     sim.close()
 
 
-def test_done_agents_leave_and_auto_reset(nets, compiled_maps):
+@pytest.mark.parametrize("name,E,N", [("loop", 4, 8), ("loop", 5, 7), ("4lane", 3, 20), ("minicity", 2, 64)])
+def test_done_agents_leave_and_auto_reset(name, E, N, nets, compiled_maps):
     """Episode boundaries (parallel_env.py:303-309; test_parallel_env.py:166-189): with
     max_episode_steps = 5 every agent is done on the 4th action step, the env reports
     dones["__all__"], and the observation handed back is the first one of the next episode."""
@@ -328,9 +329,8 @@ def test_done_agents_leave_and_auto_reset(nets, compiled_maps):
 
     from smarts_amd import _native as nat
 
-    E, N = 4, 8
-    sim, ob, cfg = _make("loop", E, N, nets, compiled_maps, 31, max_episode_steps=5, auto_reset=True,
-                         done_collision=False)
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, 31, max_episode_steps=5, auto_reset=True,
+                         done_collision=False, done_off_road=False, done_off_route=False)
     first = _host(sim.reset())
     acts = torch.zeros((E, N), dtype=torch.int8, device="cuda")
     for t in range(4):
@@ -351,6 +351,19 @@ def test_done_agents_leave_and_auto_reset(nets, compiled_maps):
     pos = out["ego_pos"].cpu().numpy().reshape(-1, 3)[:, :2]
     assert np.allclose(pos, sim.spawns[1].cpu().numpy()[:, :2])
     assert not np.allclose(pos, first["ego_pos"][:, :2])
+    # the reset observation the tick handed back is what an explicit reset of episode 1 observes:
+    # a second batch, reset twice, builds it through the other code path (k_reset + reset pass)
+    from smarts_amd.engine import BatchedSim
+
+    twin = BatchedSim(sim.cm, cfg, spawns=sim.spawns.cpu().numpy())
+    twin.reset()
+    ref = _host(twin.reset())
+    got = _host(out)
+    for k in ref:
+        if k in ("reward", "done", "learner"):
+            continue  # the auto-reset tick keeps the finishing tick's reward / done
+        assert np.array_equal(ref[k], got[k], equal_nan=True), k
+    twin.close()
     sim.close()
 
 
