@@ -1,6 +1,6 @@
 """Developer: teacher-forced run; on the first mismatching tick print controller internals of the oracle."""
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from smarts_amd.sumo_map import load_net
 from smarts_amd.map_compiler import compile_map

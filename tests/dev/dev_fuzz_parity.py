@@ -1,6 +1,6 @@
 """Developer: teacher-forced parity over many seeds / maps (a wider net than the committed tests)."""
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from smarts_amd.sumo_map import load_net
 from smarts_amd.map_compiler import compile_map
