@@ -71,11 +71,18 @@ def encode_float_action(space: ActionSpaceType, action: Any):
     return vals
 
 
+# paths kept per agent when the caller asks for the reference's full ``waypoint_paths`` (one path per
+# lane of the ego's road, plus junction branches; the shipped maps have at most 4 lanes per road)
+FULL_WINDOW_PATHS = 8
+
+
 def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: int, dt: float, auto_reset: bool,
-                              waypoint_window: Tuple[int, int] = (4, 20), num_social: int = 0,
+                              waypoint_window: Optional[Tuple[int, int]] = (4, 20), num_social: int = 0,
                               agent_ids: Optional[Sequence[str]] = None):
     """AgentInterface -> SimConfig (one interface for every agent, as FormatObs also requires,
-    format_obs.py:207-210)."""
+    format_obs.py:207-210).  ``waypoint_window`` = (paths, waypoints per path) kept in the dense
+    rows; ``None`` keeps what the reference's ``Observation`` holds: every waypoint of a path
+    (``lookahead + 1``) for up to ``FULL_WINDOW_PATHS`` paths."""
     from ..engine import SimConfig
 
     itf.validate_for_device()
@@ -102,7 +109,9 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
             lists.append(([agent_ids.index(a) for a in lst.agents_list if a in agent_ids], lst.minimum_agents_alive_in_list))
         kw["alive_lists"] = tuple(lists)
     if itf.waypoints:
-        # the dense rows keep the StdObs window (format_obs.py:42) unless the lookahead is shorter
+        # (4, 20) is the StdObs window (format_obs.py:42); rows are never longer than the lookahead
+        if waypoint_window is None:
+            waypoint_window = (FULL_WINDOW_PATHS, itf.waypoints.lookahead + 1)
         kw["wp_paths"] = waypoint_window[0]
         kw["wp_len"] = min(waypoint_window[1], itf.waypoints.lookahead + 1)
     if itf.ogm:
@@ -116,7 +125,7 @@ class BatchCore:
     """E env instances of one scenario x the agents of ``agent_specs`` on one device."""
 
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
-                 auto_reset: bool, device: str = "cuda:0", waypoint_window: Tuple[int, int] = (4, 20),
+                 auto_reset: bool, device: str = "cuda:0", waypoint_window: Optional[Tuple[int, int]] = (4, 20),
                  num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None):
         from ..engine import BatchedSim, make_spawns
         from ..scenario_build import load_compiled_map

@@ -197,10 +197,14 @@ class FormatObs:
                 "pos": np.array(rows["nb_pos"][env, slot]), "speed": np.array(rows["nb_speed"][env, slot]),
             }
         if "wp_pos" in rows and rows["wp_count"][env, slot, 0] > 0:
+            # rows of any window -> the fixed StdObs (4, 20) block (format_obs.py:565-603)
+            def window(key):
+                a = rows[key][env, slot]
+                return _pad(np.array(a[:_WAYPOINT_SHP[0], :_WAYPOINT_SHP[1]]), _WAYPOINT_SHP + a.shape[2:])
+
             waypoints = {
-                "heading": np.array(rows["wp_heading"][env, slot]), "lane_index": np.array(rows["wp_lane_index"][env, slot]),
-                "lane_width": np.array(rows["wp_lane_width"][env, slot]), "pos": np.array(rows["wp_pos"][env, slot]),
-                "speed_limit": np.array(rows["wp_speed_limit"][env, slot]),
+                "heading": window("wp_heading"), "lane_index": window("wp_lane_index"),
+                "lane_width": window("wp_lane_width"), "pos": window("wp_pos"), "speed_limit": window("wp_speed_limit"),
             }
         if "ogm" in rows:
             ogm = np.array(rows["ogm"][env, slot], dtype=np.uint8)[..., None]

@@ -42,7 +42,7 @@ class HiWayEnv:
         zoo_addrs: Optional[str] = None,
         timestep_sec: Optional[float] = None,  # deprecated alias (hiway_env.py:107-113)
         device: str = "cuda:0",
-        waypoint_window: Tuple[int, int] = (4, 20),
+        waypoint_window: Optional[Tuple[int, int]] = None,
         num_social: int = 0,
         vias: Optional[Dict[str, Sequence]] = None,
     ):
@@ -64,6 +64,8 @@ class HiWayEnv:
         self._agent_specs = agent_specs
         self._dt = float(fixed_timestep_sec)
         self._device = device
+        # (paths, waypoints per path) kept per agent; None = whole paths as in the reference's Observation
+        # (ParallelEnv falls back to the StdObs window (4, 20) for its dense rows)
         self._waypoint_window = waypoint_window
         # scripted social traffic (the accelerated path's stand-in for the scenario's SUMO flows)
         self._num_social = int(num_social)

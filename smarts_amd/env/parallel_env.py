@@ -15,6 +15,10 @@ import numpy as np
 from .core import BatchCore
 from .hiway_env import HiWayEnv, unpack_env
 
+# ParallelEnv's product is the dense StdObs rows, so envs built without an explicit window keep the
+# StdObs one (format_obs.py:42) here; a lone HiWayEnv keeps full paths for its Observation objects
+STD_WAYPOINT_WINDOW = (4, 20)
+
 EnvConstructor = Callable[[], HiWayEnv]
 
 
@@ -58,7 +62,7 @@ class ParallelEnv:
             self._core.close()
         p = self._proto
         self._core = BatchCore(p._scenario, p.agent_specs, num_envs=self._num_envs, dt=p._dt, seed=seed,
-                               auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window,
+                               auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window or STD_WAYPOINT_WINDOW,
                                num_social=p._num_social, vias=p._vias)
         self._seed = seed
         return [seed + i for i in range(self._num_envs)]

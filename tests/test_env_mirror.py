@@ -117,6 +117,9 @@ def test_sim_config_from_interface():
     assert ca.alive_min_ego == 2 and ca.alive_min_total is None and ca.alive_lists == (([1, 2], 1),)
     short = env_core.sim_config_from_interface(AgentInterface.from_type(AgentType.Laner, waypoints=Waypoints(8)), 1, 1, 0.1, False)
     assert short.wp_len == 9
+    # None = what the reference's Observation holds: whole paths
+    full = env_core.sim_config_from_interface(AgentInterface.from_type(AgentType.Laner), 1, 1, 0.1, False, waypoint_window=None)
+    assert (full.wp_paths, full.wp_len) == (env_core.FULL_WINDOW_PATHS, 33)
 
 
 def test_heading_wraps_like_the_reference():

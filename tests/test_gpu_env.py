@@ -86,7 +86,11 @@ def test_hiway_env_matches_the_oracle_on_config0(nets, compiled_maps):
             e, r = obs[a].ego_vehicle_state, ref[i]["ego"]
             assert np.allclose(e.position[:2], r["position"][:2], atol=1e-6), (t, a)
             assert e.lane_id == r["lane_id"] and e.lane_index == r["lane_index"]
-            assert [p[0].lane_id for p in obs[a].waypoint_paths] == [p[0].lane_id for p in ref[i]["waypoint_paths"][:4]]
+            # a lone HiWayEnv keeps the reference's full paths (every path, lookahead + 1 waypoints)
+            assert [p[0].lane_id for p in obs[a].waypoint_paths] == [p[0].lane_id for p in ref[i]["waypoint_paths"]]
+            assert [len(p) for p in obs[a].waypoint_paths] == [len(p) for p in ref[i]["waypoint_paths"]]
+            last, ref_last = obs[a].waypoint_paths[0][-1], ref[i]["waypoint_paths"][0][-1]
+            assert np.allclose(last.pos, ref_last.pos[:2], atol=1e-6) and last.lane_id == ref_last.lane_id
             assert [v.id for v in obs[a].neighborhood_vehicle_states] == [f"agent_{nv['slot']}-vehicle" for nv in ref[i]["neighbors"]]
         acts = {a: script[(t + i) % len(script)] for i, a in enumerate(ids)}
         obs, rewards, dones, infos = env.step(acts)
