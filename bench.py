@@ -30,7 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 ACTION_CYCLE = 64
@@ -74,9 +73,9 @@ def hbm_traffic_for(workload_key):
     return None
 
 
-def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
-    """The CPU port (oracle/: per-agent sequential Python/numpy, the shape of SMARTS._step) timed
-    on a bounded sample of the same workload.  Reported, never shipped."""
+def cpu_port_rate(net, cm, cfg_kw, seconds_budget, first_env=0):
+    """(env-steps, seconds, envs, agents, ticks) of the CPU port (oracle/: per-agent sequential
+    Python/numpy, the shape of SMARTS._step) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
     from smarts_amd.engine import SimConfig, make_spawns
@@ -86,10 +85,10 @@ def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
     kw = dict(cfg_kw)
     kw["num_envs"] = E
     cfg = SimConfig(**kw)
-    spawns = make_spawns(cm, E, N, episodes=1, seed=42)
+    spawns = make_spawns(cm, E, N, episodes=1, seed=42, first_env=first_env)
     ob = parity.OracleBatch(net, cm, cfg, spawns[0])
     ob.reset_observe()
-    acts = action_stream(E, N, 42, 0)
+    acts = action_stream(E, N, 42, first_env)
     t0 = time.perf_counter()
     ticks = 0
     while True:
@@ -98,15 +97,96 @@ def cpu_baseline(net, cm, cfg_kw, seconds_budget=15.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or ticks >= 400:
             break
+    return E * ticks, el, E, N, ticks
+
+
+def workload_config(config, envs=None, vehicles=None, scenario=None):
+    from smarts_amd import lidar as lidar_mod
+
+    preset = CONFIGS[config]
+    E, N = envs or preset["envs"], vehicles or preset["vehicles"]
+    cfg_kw = dict(num_envs=E, num_vehicles=N, dt=0.1, waypoints=True, neighbors=True, nb_radius=50.0, nb_max=10,
+                  wp_paths=4, wp_len=20, wp_lookahead=32, auto_reset=True)
+    cfg_kw.update(preset["extra"])
+    if cfg_kw.get("lidar") == "planar100":
+        cfg_kw["lidar"] = lidar_mod.Planar100
+    return preset, scenario or preset["scenario"], cfg_kw
+
+
+def cpu_worker(args):
+    """Child of the all-cores CPU leg: one process = one env group, as ParallelEnv runs them
+    (parallel_env.py:96-122).  Never touches the GPU (no torch import)."""
+    from smarts_amd.map_compiler import compile_map
+    from smarts_amd.sumo_map import load_net
+
+    _, scenario, cfg_kw = workload_config(args.config, args.envs_per_gpu, args.vehicles, args.scenario)
+    net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", scenario))
+    steps, el, *_ = cpu_port_rate(net, compile_map(net), cfg_kw, args.cpu_seconds, first_env=4 * args.cpu_worker)
+    print(json.dumps({"env_steps": steps, "seconds": el}))
+
+
+def cpu_all_cores(args, seconds_budget=8.0):
+    """P processes x their own envs, P = the host cores this job may use
+    (at most 16, the GPU box's share).  Children are started as ordinary subprocesses with the
+    GPU hidden and no profiler preload, and only after this process has finished its GPU work."""
+    import subprocess
+
+    if any("rocprof" in v.lower() for v in (os.environ.get("LD_PRELOAD", ""), os.environ.get("ROCP_TOOL_LIBRARIES", ""))):
+        return None  # under the profiler every child would attach to the GPU
+    P = max(1, min(len(os.sched_getaffinity(0)), 16))
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+    env.update(HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
+               MKL_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--cpu-seconds", str(seconds_budget)]
+    for flag, val in (("--envs-per-gpu", args.envs_per_gpu), ("--vehicles", args.vehicles), ("--scenario", args.scenario)):
+        if val is not None:
+            cmd += [flag, str(val)]
+    procs = [subprocess.Popen(cmd + ["--cpu-worker", str(w)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+             for w in range(P)]
+    rate = 0.0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=seconds_budget * 6 + 60)
+            rec = json.loads(out.decode().strip().splitlines()[-1])
+            rate += rec["env_steps"] / rec["seconds"]
+        except Exception:
+            pr.kill()
+            return None
+    return {"value": rate, "unit": "env-steps/s", "cores": P,
+            "sample": f"{P} processes, each the single-core sample on its own envs for ~{seconds_budget:.0f} s, rates summed"}
+
+
+def cpu_baseline(net, cm, cfg_kw, args, seconds_budget=15.0):
+    """The CPU port timed on a bounded sample of the same workload.  Reported, never shipped."""
+    steps, el, E, N, ticks = cpu_port_rate(net, cm, cfg_kw, seconds_budget)
     return {
-        "value": E * ticks / el,
+        "value": steps / el,
         "unit": "env-steps/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{E} envs x {N} agents x {ticks} ticks of the same workload (same map, sensors, spawns and "
                   f"action stream), {el:.1f} s on one host core; the reference itself is single-threaded Python "
                   "per env",
+        "all_cores": cpu_all_cores(args),
     }
+
+
+def copy_peak_gbps(device, torch):
+    """Measured device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer: the
+    practical HBM ceiling on this box, quoted beside the datasheet peak."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    del src, dst
+    return 2.0 * n * 10 / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
 def main():
@@ -120,7 +200,13 @@ def main():
     ap.add_argument("--scenario", default=None)
     ap.add_argument("--phase-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return cpu_worker(args)
+
+    import torch
 
     from smarts_amd import build, sharding
     from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
@@ -139,20 +225,11 @@ def main():
     if world > 1:
         sharding.barrier()
 
-    from smarts_amd import lidar as lidar_mod
-
-    preset = CONFIGS[args.config]
-    E = args.envs_per_gpu or preset["envs"]
-    N = args.vehicles or preset["vehicles"]
-    scenario = args.scenario or preset["scenario"]
+    preset, scenario, cfg_kw = workload_config(args.config, args.envs_per_gpu, args.vehicles, args.scenario)
+    E, N = cfg_kw["num_envs"], cfg_kw["num_vehicles"]
     plan = sharding.ShardPlan(total_envs=E * world, world_size=world, rank=rank)
     net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", scenario))
     cm = compile_map(net)
-    cfg_kw = dict(num_envs=E, num_vehicles=N, dt=0.1, waypoints=True, neighbors=True, nb_radius=50.0, nb_max=10,
-                  wp_paths=4, wp_len=20, wp_lookahead=32, auto_reset=True)
-    cfg_kw.update(preset["extra"])
-    if cfg_kw.get("lidar") == "planar100":
-        cfg_kw["lidar"] = lidar_mod.Planar100
     cfg = SimConfig(**cfg_kw)
     spawns = make_spawns(cm, E, N, episodes=4, seed=42, first_env=plan.first_env)
     sim = BatchedSim(cm, cfg, device=device, spawns=spawns)
@@ -198,6 +275,7 @@ def main():
         phase_ms = sim.read_phase_ms().mean(axis=0)
         sim.set_timing(0)
 
+    copy_peak = copy_peak_gbps(device, torch) if rank == 0 else None
     if rank == 0:
         total_envs = E * world
         env_steps_per_s = total_envs * args.steps / elapsed
@@ -257,6 +335,7 @@ def main():
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
+                "measured_copy_peak": copy_peak,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
@@ -271,11 +350,15 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(net, cm, cfg_kw)
+            sim.close()
+            sim = None
+            torch.cuda.synchronize()
+            line["cpu_baseline"] = cpu_baseline(net, cm, cfg_kw, args)
         elif world == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    sim.close()
+    if sim is not None:
+        sim.close()
     if world > 1:
         sharding.barrier()
         dist.destroy_process_group()

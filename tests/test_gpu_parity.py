@@ -304,6 +304,42 @@ def test_via_sensor(nets, compiled_maps):
     sim.close()
 
 
+def test_collision_thresholds_of_the_reference(nets, compiled_maps):
+    """test_collision.py:206-282 through the C-ABI: standing passenger boxes packed around a
+    standing ego, 0.0501 m clear on every side -> no collision event; 0.0499 m -> every pair that
+    touches reports it (and is done: DoneCriteria.collision)."""
+    import torch
+
+    from smarts_amd import _native as nat
+    from smarts_amd.engine import BatchedSim, SimConfig, lane_heading, make_spawns
+    from smarts_amd.vias import _position_at_shape_offset
+
+    cm = compiled_maps("4lane")
+    E, N = 2, 5
+    cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0)
+    spawns = make_spawns(cm, E, N, episodes=1, seed=5)
+    shape = cm.lane_shape(cm.lane_ids.index("edge-south-SN_0"))
+    cx, cy = _position_at_shape_offset(shape, 40.0)
+    h = lane_heading(shape, 0)
+    f, r = np.array([-np.sin(h), np.cos(h)]), np.array([np.cos(h), np.sin(h)])
+    for e, sep in enumerate((0.0501, 0.0499)):
+        ring = [(0.0, 0.0), (3.68 + sep, 0.0), (0.0, 1.47 + sep), (-(3.68 + sep), 0.0), (0.0, -(1.47 + sep))]
+        for k, (along, across) in enumerate(ring):
+            x, y = np.array([cx, cy]) + along * f + across * r
+            spawns[:, e * N + k] = (x, y, h, 0.0)
+    sim = BatchedSim(cm, cfg, spawns=spawns)
+    ob = parity.OracleBatch(nets("4lane"), cm, cfg, spawns[0])
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    acts = np.full((E, N), nat.ACTION_SLOW_DOWN, dtype=np.int8)  # target speed 0: nobody moves
+    d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-5, where="t0 ") == []
+    hit = d["events"][:, nat.EV_COLLISIONS].reshape(E, N)
+    assert not hit[0].any() and hit[1].all()
+    assert not d["done"].reshape(E, N)[0].any() and d["done"].reshape(E, N)[1].all()
+    sim.close()
+
+
 def test_free_running_rollout_pose_bar(nets, compiled_maps):
     import torch
 

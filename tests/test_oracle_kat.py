@@ -122,3 +122,34 @@ def test_golden_equally_spaced_vector_from_survey():
     assert all(w.pos[1] == 0.0 for w in wps)
     assert wps[0].heading == -1.5707963267948966
     assert wps[0].lane_index == 0 and wps[0].lane_width == 3.2 and wps[0].speed_limit == 16.67
+
+
+def _still(x, y, heading):
+    return VehicleBody(x, y, heading, 0.0)
+
+
+def test_contact_rule_reproduces_the_reference_collision_geometry():
+    """smarts/core/tests/test_collision.py:86-282 restated for the footprint rule that stands in for
+    Bullet's getClosestPoints(distance=0.05) (chassis.py:64-78): crossed boxes at one centre collide
+    (:86-106), 10 m apart do not (:109-127), and a passenger box packed 0.0501 m clear of the ego on
+    each side reports nothing (:206-282) while 0.0499 m does."""
+    from oracle.dynamics import CHASSIS_LENGTH, CHASSIS_WIDTH
+    from oracle.sim import COLLISION_LEEWAY, boxes_within
+
+    assert (CHASSIS_LENGTH, CHASSIS_WIDTH) == (3.68, 1.47)  # VEHICLE_CONFIGS["passenger"] (vehicle.py:101)
+    ego = _still(0.0, 0.0, -0.5 * math.pi)
+    assert boxes_within(ego, _still(0.0, 0.0, 0.0), COLLISION_LEEWAY)  # a "plus": no corner inside the other box
+    assert not boxes_within(ego, _still(0.0, 10.0, 0.0), COLLISION_LEEWAY)
+    ego = _still(0.0, 0.0, 0.0)
+    for sep, touching in ((0.0501, False), (0.0499, True)):
+        ring = [(0.0, CHASSIS_LENGTH + sep), (CHASSIS_WIDTH + sep, 0.0), (0.0, -(CHASSIS_LENGTH + sep)), (-(CHASSIS_WIDTH + sep), 0.0)]
+        for x, y in ring:
+            assert boxes_within(ego, _still(x, y, 0.0), COLLISION_LEEWAY) is touching, (sep, x, y)
+            assert boxes_within(_still(x, y, 0.0), ego, COLLISION_LEEWAY) is touching
+    # rotated pair: corner of one 0.05 -/+ 1e-4 from the side of the other
+    for gap, touching in ((0.0499, True), (0.0501, False)):
+        h = math.pi / 4
+        # the nearest corner of a box at heading pi/4 lies (L/2 + W/2) / sqrt(2) left of its centre
+        reach = (0.5 * CHASSIS_LENGTH + 0.5 * CHASSIS_WIDTH) / math.sqrt(2.0)
+        other = _still(0.5 * CHASSIS_WIDTH + gap + reach, 0.0, h)
+        assert boxes_within(ego, other, COLLISION_LEEWAY) is touching
