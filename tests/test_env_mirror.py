@@ -207,3 +207,15 @@ def test_lane_ttc_and_std_obs_match_the_reference_functions(compiled_maps):
             assert np.array_equal(d.ego["pos"], s.ego["pos"]) and d.ego["speed"] == s.ego["speed"]
             checked += 1
     assert checked >= 16
+
+
+def test_make_mirrors_the_registered_id():
+    # smarts/env/__init__.py:22-25 registers "hiway-v0"; gym.make("smarts.env:hiway-v0", ...)
+    from smarts_amd import env as env_pkg
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Laner))
+    e = env_pkg.make("smarts.env:hiway-v0", scenarios=["scenarios/loop"], agent_specs={"A": spec}, headless=True, seed=7)
+    assert isinstance(e, env_pkg.HiWayEnv) and e.agent_specs == {"A": spec} and e.seed(7) == 7
+    e.close()
+    with pytest.raises(ValueError):
+        env_pkg.make("smarts.env:highway-v9", scenarios=["scenarios/loop"], agent_specs={"A": spec})
