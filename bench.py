@@ -218,8 +218,9 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dev_index = sharding.local_device_index(local_rank)
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if rank == 0:
         build.build()
     if world > 1:

@@ -48,13 +48,22 @@ def init_process_group(backend: Optional[str] = None):
     rank, local_rank, world = env_from_dist()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SMX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             # one process per GPU: bind the rank to its device before the first collective
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def local_device_index(local_rank: int) -> int:
+    """The GPU of this rank: ``local_rank`` (one process per GPU).  ``SMX_REHEARSE_ONE_GPU=1`` folds
+    the ranks onto the devices that exist — a rehearsal of the multi-rank path on a one-GPU box
+    (with ``SMX_DIST_BACKEND=gloo``; RCCL refuses two ranks on one device), never a measurement."""
+    if os.environ.get("SMX_REHEARSE_ONE_GPU") == "1":
+        return local_rank % max(torch.cuda.device_count(), 1)
+    return local_rank
 
 
 def barrier():
