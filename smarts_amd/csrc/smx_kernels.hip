@@ -571,6 +571,8 @@ struct WpRows {
   float *heading, *width, *speed;
   int16_t* lid;
   int8_t* lidx;
+  int cached_lane;  // lane whose index is held in cached_index (-1: none): consecutive waypoints
+  int cached_index; // mostly share their lane, and a look-up per waypoint stalls its own store
 };
 
 __device__ __forceinline__ WpRows wp_rows(const smx_outputs& o, size_t gid, int P, int W, int slot) {
@@ -582,10 +584,16 @@ __device__ __forceinline__ WpRows wp_rows(const smx_outputs& o, size_t gid, int 
   r.speed = o.wp_speed_limit + q;
   r.lid = o.wp_lane_id + q;
   r.lidx = o.wp_lane_index + q;
+  r.cached_lane = -1;
+  r.cached_index = 0;
   return r;
 }
 
-__device__ __forceinline__ void wp_put(const MapDev& m, const WpRows& r, int i, const WaypointOut& w) {
+__device__ __forceinline__ void wp_put(const MapDev& m, WpRows& r, int i, const WaypointOut& w) {
+  if (w.lane != r.cached_lane) {
+    r.cached_lane = w.lane;
+    r.cached_index = m.lane_index[w.lane];
+  }
   r.pos[i * 3 + 0] = w.x;
   r.pos[i * 3 + 1] = w.y;
   r.pos[i * 3 + 2] = 0.0;
@@ -593,7 +601,7 @@ __device__ __forceinline__ void wp_put(const MapDev& m, const WpRows& r, int i, 
   r.width[i] = (float)w.width;
   r.speed[i] = (float)w.speed;
   r.lid[i] = (int16_t)w.lane;
-  r.lidx[i] = (int8_t)m.lane_index[w.lane];
+  r.lidx[i] = (int8_t)r.cached_index;
 }
 
 __device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
@@ -618,6 +626,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
+  SMX_TSTAMP(tw0);
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
@@ -646,6 +655,8 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
     const PathSeeds seed = load_seeds(a, gid, total);
     const int lookahead = c.wp_lookahead;
     int n_paths_total = 0;
+    SMX_TSTAMP(tw1);
+    SMX_TACC(0, tw0, tw1);
     if (seed.road >= 0 && !(a.debug_skip & 16)) {
       // ---- the guess: seed lane p holds exactly one path
       const int start = (p0 < seed.n_lanes) ? seed_start(m, seed, p0, px, py) : -1;
@@ -660,7 +671,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         bs.reset();
         do {
           if (cnt == 0 && prov < P) {
-            const WpRows rows = wp_rows(o, gid, P, W, prov);
+            WpRows rows = wp_rows(o, gid, P, W, prov);
             const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, W,
                                               [&](int i, const WaypointOut& w) {
                                                 if (i == 0) {
@@ -703,7 +714,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
             const bool kept = idx < P && (idx % SMX_WP_LANES) == p0;
             const bool first_path = (idx == 0 && p0 == 0);
             if (kept || first_path) {
-              const WpRows rows = wp_rows(o, gid, P, W, kept ? idx : 0);
+              WpRows rows = wp_rows(o, gid, P, W, kept ? idx : 0);
               const int n = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, SMX_BLOCK, kept ? W : 1,
                                                 [&](int i, const WaypointOut& w) {
                                                   if (first_path && i == 0) {
@@ -728,6 +739,8 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         n_paths_total = __shfl(idx, 0, SMX_WP_LANES);  // lane 0 counts them all
       }
     }
+    SMX_TSTAMP(tw2);
+    SMX_TACC(1, tw1, tw2);
     // rows of the paths that do not exist
     for (int slot = n_paths_total + ((p0 - n_paths_total) & (SMX_WP_LANES - 1)); slot < P; slot += SMX_WP_LANES) {
       wp_zero(wp_rows(o, gid, P, W, slot), 0, W);
@@ -789,6 +802,8 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
     if (o.learner) o.learner[gid] = (float)(dist - last_dist);
   }
   *trip_has_wp_p = trip_has_wp ? 1 : 0;  // the flags word itself is not written here (the observe role owns it)
+  SMX_TSTAMP(tw3);
+  SMX_TACC(3, tw0, tw3);
 }
 
 __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int block) {
@@ -902,6 +917,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
   const SharedPose* env_pose = pose + env_local * n_veh;
 
+  SMX_TSTAMP(to0);
   VehState s = {0, 0, 0, 0, 0, 0, 0};
   int flags = 0;
   bool alive = false;
@@ -930,6 +946,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     p.alive = (valid && alive) ? 1 : 0;
   }
   __syncthreads();
+  SMX_TSTAMP(to1);
+  SMX_TACC(7, to0, to1);
 
   const bool first = (flags & SMX_F_FIRST) != 0;
   const bool social = (flags & SMX_F_SOCIAL) != 0;
@@ -1079,6 +1097,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
       o.nb_count[gid] = (uint8_t)(cnt > 255 ? 255 : cnt);
     }
 
+    SMX_TSTAMP(to2);
+    SMX_TACC(8, to1, to2);
     // ---- driven path (sensors.py:842-877): running length of the last window
     bool is_not_moving = false;
     if (a.st.driven_path != nullptr) {
@@ -1225,6 +1245,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     }
   }
   if (valid) a.st.facts_i32[(size_t)SMX_FI_FLAGS_NEXT * total + gid] = new_flags;
+  SMX_TSTAMP(to3);
+  SMX_TACC(6, to0, to3);
 }
 
 // =================================================================================

@@ -498,6 +498,7 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
   const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
 
   // ---- pass 1
+  SMX_TSTAMP(te0);
   int nk = 0;
   double D = 0.0;
   {
@@ -518,6 +519,8 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
   }
   const int n = w.n;
   const int lane0 = r0.lane;
+  SMX_TSTAMP(te1);
+  SMX_TACC(4, te0, te1);
   if (n == 1) {
     // :1379-1390 (a one-point path): the lanepoint itself, not the projection
     if (max_emit > 0) {
@@ -545,6 +548,9 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
   Unwrap uw;
   uw.start(jh);
   smx_lp_rec q = (nk > 0) ? load_lp(m, knots[0], 44) : r0;
+  // width / speed limit of knot j's lane, carried from knot to knot: most knots share their lane,
+  // and a table look-up per knot would put a dependent load in front of every segment
+  double wj = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)], sj = m.lane_speed[jlane];
   for (int k = 0; k < nk && i < n_emit; ++k) {
     const smx_lp_rec cur = q;
     if (k + 1 < nk) q = load_lp(m, knots[(k + 1) * kstride], 45);  // prefetch the next knot
@@ -555,14 +561,18 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     const int qlane = cur.lane;
     // waypoints with jcum <= t < qcum interpolate on [j, j+1]; np.interp's slope
     // (dy[j+1] - dy[j]) / (dx[j+1] - dx[j]) is the same for every waypoint of the segment
+    double wq = wj, sq = sj;
+    if (qlane != jlane) {
+      wq = m.lane_width[SMX_BCHK(18, qlane, m.n_lanes)];
+      sq = m.lane_speed[qlane];
+    }
     if (i < n_emit && t < qcum) {
       const double den = qcum - jcum;
       const double sx = (qx - jx) / den, sy = (qy - jy) / den, sh = (qh - jh) / den;
-      const double wj = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)], sj = m.lane_speed[jlane];
       double sw = 0.0, ss = 0.0;
       if (qlane != jlane) {
-        sw = (m.lane_width[qlane] - wj) / den;
-        ss = (m.lane_speed[qlane] - sj) / den;
+        sw = (wq - wj) / den;
+        ss = (sq - sj) / den;
       }
       do {
         WaypointOut o;
@@ -596,6 +606,8 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     jh = qh;
     jcum = qcum;
     jlane = qlane;
+    wj = wq;
+    sj = sq;
   }
   // waypoints at (or beyond) the last knot
   while (i < n_emit) {
@@ -603,13 +615,15 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     o.x = jx;
     o.y = jy;
     o.heading = wrap_heading(jh);
-    o.width = m.lane_width[jlane];
-    o.speed = m.lane_speed[jlane];
+    o.width = wj;
+    o.speed = sj;
     o.lane = (t > jcum) ? jlane : strict_lane;
     emit(i, o);
     ++i;
     t = (i == n - 1) ? D : (double)i * step;
   }
+  SMX_TSTAMP(te2);
+  SMX_TACC(5, te1, te2);
   return n;
 }
 
