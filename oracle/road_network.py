@@ -479,6 +479,14 @@ class ORoadNetwork:
             self._lanes[lane_id] = lane
         return lane
 
+    def lane_bands(self):
+        """(centre-line shape, width) of every lane — what the road mesh is built from
+        (sumo_road_network.py:986-1019 buffers each lane shape by half its width)."""
+        if getattr(self, "_bands", None) is None:
+            self._bands = [([(float(p[0]), float(p[1])) for p in sl.getShape(False)], float(sl.getWidth()))
+                           for sl in self._all_lanes]
+        return self._bands
+
     def road_by_id(self, road_id):
         road = self._roads.get(road_id)
         if road is None:

@@ -48,6 +48,47 @@ def ogm(ego, vehicles, width, height, resolution):
     return grid
 
 
+def dagm(ego, lanes, width, height, resolution):
+    """Drivable-area grid map (DrivableAreaGridMapSensor, sensors.py:675-716) for `ego`: (height, width)
+    uint8, the OGM's camera (sensors.py:651-672: centred on the vehicle, up = its heading, np.flipud).
+    The reference renders the road mesh — every lane's centre line buffered by half its width
+    (sumo_road_network.py:986-1019) — with Panda3D, which is absent; restated as: a pixel is 255 when its
+    centre is within half the lane width of a segment of that lane's centre line.  PARITY UNPINNED
+    beyond the reference's own check (non-zero within +-2 px of on-road vehicles, test_observations.py:150-153).
+
+    `lanes`: iterable of (shape [(x, y), ...], width) — every lane of the map, internal lanes included."""
+    grid = np.zeros((height, width), dtype=np.uint8)
+    h = ego.heading
+    rx, ry = math.cos(h), math.sin(h)
+    fx, fy = -math.sin(h), math.cos(h)
+    for shape, lane_width in lanes:
+        hw = 0.5 * lane_width
+        for (x1, y1), (x2, y2) in zip(shape[:-1], shape[1:]):
+            d1x, d1y, d2x, d2y = x1 - ego.x, y1 - ego.y, x2 - ego.x, y2 - ego.y
+            ax, ay = d1x * rx + d1y * ry, d1x * fx + d1y * fy
+            bx, by = d2x * rx + d2y * ry, d2x * fx + d2y * fy
+            # bounding box of the band in pixels (a pure speed-up: pixels outside cannot pass the test)
+            c0 = int(math.floor((min(ax, bx) - hw) / resolution + 0.5 * width - 0.5)) - 1
+            c1 = int(math.ceil((max(ax, bx) + hw) / resolution + 0.5 * width - 0.5)) + 1
+            r0 = int(math.floor(0.5 * height - 0.5 - (max(ay, by) + hw) / resolution)) - 1
+            r1 = int(math.ceil(0.5 * height - 0.5 - (min(ay, by) - hw) / resolution)) + 1
+            c0, r0, c1, r1 = max(c0, 0), max(r0, 0), min(c1, width - 1), min(r1, height - 1)
+            if c0 > c1 or r0 > r1:
+                continue
+            px = (np.arange(c0, c1 + 1) + 0.5 - 0.5 * width) * resolution
+            py = (0.5 * height - (np.arange(r0, r1 + 1) + 0.5)) * resolution
+            X, Y = np.meshgrid(px, py)
+            # squared point / segment distance, the arithmetic of sim._seg_point_dist2
+            dx, dy = bx - ax, by - ay
+            ll = dx * dx + dy * dy
+            t = np.zeros_like(X) if ll == 0.0 else ((X - ax) * dx + (Y - ay) * dy) / ll
+            t = np.minimum(1.0, np.maximum(0.0, t))
+            ex, ey = ax + t * dx - X, ay + t * dy - Y
+            inside = ex * ex + ey * ey <= hw * hw
+            grid[r0:r1 + 1, c0:c1 + 1][inside] = 255
+    return grid
+
+
 def quaternion_from_euler(roll, pitch, yaw):
     """pybullet.getQuaternionFromEuler -> (x, y, z, w)."""
     cr, sr = math.cos(roll * 0.5), math.sin(roll * 0.5)

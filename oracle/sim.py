@@ -54,6 +54,7 @@ class AgentConfig:
     alive_lists: tuple = ()  # ((agent slots), minimum alive) pairs
     action_space: str = "Lane"  # Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
     ogm: Optional[tuple] = None  # (width, height, resolution) — OGM (agent_interface.py:42-51)
+    dagm: Optional[tuple] = None  # (width, height, resolution) — DrivableAreaGridMap (agent_interface.py:29-38)
     lidar_rays: Optional[np.ndarray] = None  # base rays [R, 3] (sensors_extra.base_rays)
 
 
@@ -386,6 +387,8 @@ class OracleEnv:
         o["waypoint_paths"] = waypoint_paths if cfg.waypoints_lookahead is not None else None
         if cfg.ogm is not None:  # sensors.py:303-305
             o["ogm"] = sx.ogm(b, [ob for _, ob in alive_states], *cfg.ogm)
+        if cfg.dagm is not None:  # sensors.py:307-312
+            o["dagm"] = sx.dagm(b, rmap.lane_bands(), *cfg.dagm)
         if cfg.lidar_rays is not None:  # sensors.py:297-301
             o["lidar"] = sx.lidar(b, [ob for j, ob in alive_states if j != i], cfg.lidar_rays)
         if self.vias[i]:

@@ -25,7 +25,7 @@ EV = {name.upper(): i for i, name in enumerate(EVENT_NAMES)}
 ACTION_SPACES = {"Lane": 0, "Continuous": 1, "ActuatorDynamic": 2, "LaneWithContinuousSpeed": 3, "Trajectory": 4}
 TRAJ_COLS = 11
 PHASES = ["control", "scan", "ogm", "sensors", "commit", "reset"]
-SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR = 1, 2, 4, 8, 16
+SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR, SENSOR_DAGM = 1, 2, 4, 8, 16, 32
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
                 "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
                 "LV1_LAT", "AV1_Z", "PATH_SUM", "PREV_X", "PREV_Y"]
@@ -54,6 +54,7 @@ class SmxConfig(C.Structure):
         ("lidar_max_distance", _f64), ("action_space", _i32), ("num_social", _i32), ("social_speed_factor", _f64), ("via_max", _i32),
         ("alive_min_ego", _i32), ("alive_min_total", _i32), ("alive_lists", _i32), ("alive_list_min", _i32 * 4),
         ("alive_list_mask", C.c_uint64 * 4),
+        ("dagm_width", _i32), ("dagm_height", _i32), ("dagm_resolution", _f64),
     ]
 
 
@@ -90,7 +91,7 @@ OUTPUT_FIELDS = [
     "ego_pos", "ego_f32", "ego_lane", "events", "reward", "dist", "done", "active", "env_done", "learner",
     "wp_pos", "wp_heading", "wp_lane_width", "wp_speed_limit", "wp_lane_index", "wp_lane_id", "wp_count",
     "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
-    "ogm", "lidar_hit", "lidar_point",
+    "ogm", "lidar_hit", "lidar_point", "dagm",
 ]
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("learner"), "via_hit")
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_hit"), "via_near_count")

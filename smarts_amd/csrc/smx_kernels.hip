@@ -24,6 +24,7 @@
 // (reference: one process per env, parallel_env.py:96-122): no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,7 @@ struct KernelArgs {
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
   int debug_skip;
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
+  double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
 };
 
 #define SF(field) a.st.f64[(size_t)(field) * total + gid]
@@ -893,6 +895,10 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
     const size_t n = (size_t)c.ogm_width * c.ogm_height;
     for (size_t k = 0; k < n; ++k) o.ogm[gid * n + k] = 0;
   }
+  if ((c.sensors & SMX_SENSOR_DAGM) && o.dagm) {
+    const size_t n = (size_t)c.dagm_width * c.dagm_height;
+    for (size_t k = 0; k < n; ++k) o.dagm[gid * n + k] = 0;
+  }
   if ((c.sensors & SMX_SENSOR_LIDAR) && o.lidar_hit) {
     for (int k = 0; k < c.lidar_rays; ++k) {
       o.lidar_hit[gid * (size_t)c.lidar_rays + k] = 0;
@@ -1372,6 +1378,76 @@ __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
 }
 
 // =================================================================================
+// DAGM role: drivable-area grid map (DrivableAreaGridMapSensor, sensors.py:675-716): one workgroup per
+// observing vehicle, the tile in LDS.  The reference renders the road mesh (lane centre lines
+// buffered by half the lane width) through the OGM's camera; here a pixel is 255 when its centre
+// lies within half a lane width of a segment of a lane centre line (DESIGN.md "Substitutions").
+// The segment grid only prunes: a segment that can reach the view lies within the view's
+// circumscribed circle grown by the widest half width, so its bounding box meets the visited cells.
+// Wavefronts take segments, lanes the pixels of a segment's bounding box; a segment listed in
+// several cells is drawn again (same value).
+// =================================================================================
+__device__ __forceinline__ void dagm_role(const KernelArgs& a, const int block) {
+  extern __shared__ __align__(16) unsigned char tile[];
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = (size_t)block;
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  const bool live = (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
+  if (!live) return;  // uniform for the whole workgroup
+  const int W = c.dagm_width, H = c.dagm_height;
+  const int bytes = W * H;
+  for (int k = threadIdx.x; k < bytes / 4; k += SMX_BLOCK) reinterpret_cast<int*>(tile)[k] = 0;
+  __syncthreads();
+  const double res = c.dagm_resolution;
+  const double ex0 = SF(SMX_S_X), ey0 = SF(SMX_S_Y), eh = wrap_heading(SF(SMX_S_HEADING));
+  const double rx = cos(eh), ry = sin(eh);    // ego right axis
+  const double fx = -sin(eh), fy = cos(eh);   // ego forward axis
+  const double vw = 0.5 * W * res, vh = 0.5 * H * res;
+  const double reach = sqrt(vw * vw + vh * vh) + a.dagm_reach + 1e-6;
+  int cx0 = (int)floor((ex0 - reach - m.sg_x0) / m.sg_cell), cx1 = (int)floor((ex0 + reach - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((ey0 - reach - m.sg_y0) / m.sg_cell), cy1 = (int)floor((ey0 + reach - m.sg_y0) / m.sg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.sg_nx - 1);
+  cy1 = min(cy1, m.sg_ny - 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = SMX_BLOCK >> 6;
+  for (int gy = cy0; gy <= cy1; ++gy) {
+    if (cx0 > cx1) break;
+    const int row = gy * m.sg_nx;
+    // cells of one grid row are contiguous in the member array
+    const int m0 = m.sg_off[row + cx0], m1 = m.sg_off[row + cx1 + 1];
+    for (int k = m0 + wave; k < m1; k += n_waves) {
+      const smx_seg_rec s = m.sg_rec[k];
+      const double hw = 0.5 * m.lane_width[s.lane];
+      // end points in the ego frame (x to the right, y ahead)
+      const double d1x = s.x1 - ex0, d1y = s.y1 - ey0, d2x = s.x2 - ex0, d2y = s.y2 - ey0;
+      const double ax = d1x * rx + d1y * ry, ay = d1x * fx + d1y * fy;
+      const double bx = d2x * rx + d2y * ry, by = d2x * fx + d2y * fy;
+      // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
+      int c0 = (int)floor((fmin(ax, bx) - hw) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((fmax(ax, bx) + hw) / res + 0.5 * W - 0.5) + 1;
+      int r0 = (int)floor(0.5 * H - 0.5 - (fmax(ay, by) + hw) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (fmin(ay, by) - hw) / res) + 1;
+      c0 = max(c0, 0);
+      r0 = max(r0, 0);
+      c1 = min(c1, W - 1);
+      r1 = min(r1, H - 1);
+      if (c0 > c1 || r0 > r1) continue;
+      const int bw = c1 - c0 + 1, n_px = bw * (r1 - r0 + 1);
+      for (int q = lane; q < n_px; q += 64) {
+        const int r = r0 + q / bw, col = c0 + q % bw;
+        const double px = (col + 0.5 - 0.5 * W) * res, py = (0.5 * H - (r + 0.5)) * res;
+        if (seg_point_dist2(px, py, ax, ay, bx, by) <= hw * hw) tile[r * W + col] = 255;
+      }
+    }
+  }
+  __syncthreads();
+  int4* dst = reinterpret_cast<int4*>(a.out.dagm + gid * (size_t)bytes);
+  for (int k = threadIdx.x; k < bytes / 16; k += SMX_BLOCK) dst[k] = reinterpret_cast<const int4*>(tile)[k];
+}
+
+// =================================================================================
 // lidar role: lidar sensor (LidarSensor sensors.py:797-827, Lidar lidar.py:58-134): one wavefront per
 // observing vehicle, lanes over rays.  Ray i = [origin, origin + base_ray[i]], origin = vehicle
 // position + (0, 0, 1); base rays come from the host (they do not rotate with the vehicle,
@@ -1566,6 +1642,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_first(const KernelArgs a) {
 // occupancy; forcing more wavefronts per SIMD onto k_waypoints / k_observe by waves_per_eu cost more
 // in spills than it won: +20 % on loop 4096 x 32) and OGM tiles too large to ride along as dynamic LDS of every k_sensors workgroup
 __global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) { ogm_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_dagm(const KernelArgs a) { dagm_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
@@ -1631,6 +1708,7 @@ struct smx_handle_s {
   int32_t* via_off_dev;
   int32_t n_vias;
   double heading_gain_pos, lateral_gain_pos;
+  double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
   bool timing;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2*i] start, [2*i+1] stop
@@ -1737,6 +1815,10 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
       (c.ogm_width < 1 || c.ogm_height < 1 || (c.ogm_width * c.ogm_height) % 16 != 0 ||
        c.ogm_width * c.ogm_height > 64 * 1024 || !(c.ogm_resolution > 0.0)))
     return fail(h, SMX_ERR_INVALID, "ogm: need width*height a multiple of 16 and at most 65536, resolution > 0");
+  if ((c.sensors & SMX_SENSOR_DAGM) &&
+      (c.dagm_width < 1 || c.dagm_height < 1 || (c.dagm_width * c.dagm_height) % 16 != 0 ||
+       c.dagm_width * c.dagm_height > 64 * 1024 || !(c.dagm_resolution > 0.0)))
+    return fail(h, SMX_ERR_INVALID, "dagm: need width*height a multiple of 16 and at most 65536, resolution > 0");
   if ((c.sensors & SMX_SENSOR_LIDAR) && (c.lidar_rays < 1 || c.lidar_rays > 65536))
     return fail(h, SMX_ERR_INVALID, "lidar: need 1 <= lidar_rays <= 65536");
   if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (c.nb_max < 1 || c.nb_max > 127))
@@ -1787,6 +1869,10 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
         r.lane >= t->n_lanes || r.hops < 1)
       return fail(h, SMX_ERR_INVALID, "successor record out of range");
   }
+  for (int i = 0; i < t->sg_off[sg_cells]; ++i)
+    if (t->sg_rec[i].lane < 0 || t->sg_rec[i].lane >= t->n_lanes) return fail(h, SMX_ERR_INVALID, "segment record out of range");
+  h->dagm_reach = 0.0;
+  for (size_t i = 0; i < nl; ++i) h->dagm_reach = std::max(h->dagm_reach, 0.5 * t->lane_width[i]);
 #define ADD(field, count, type) size_t off_##field = w.add(t->field, (size_t)(count) * sizeof(type))
   ADD(lane_road, nl, int32_t);
   ADD(lane_index, nl, int32_t);
@@ -1906,6 +1992,7 @@ static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp
   if (c.via_max > 0 && h->n_vias > 0 && (!o->via_near || !o->via_near_count || !o->via_hit))
     return fail(h, SMX_ERR_INVALID, "vias are set but a via output buffer is null");
   if ((c.sensors & SMX_SENSOR_OGM) && !o->ogm) return fail(h, SMX_ERR_INVALID, "ogm sensor enabled but out.ogm is null");
+  if ((c.sensors & SMX_SENSOR_DAGM) && !o->dagm) return fail(h, SMX_ERR_INVALID, "dagm sensor enabled but out.dagm is null");
   if ((c.sensors & SMX_SENSOR_LIDAR) && (!o->lidar_hit || !o->lidar_point))
     return fail(h, SMX_ERR_INVALID, "lidar sensor enabled but an output buffer is null");
   if ((c.sensors & SMX_SENSOR_LIDAR) && !h->lidar_rays)
@@ -2000,6 +2087,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const size_t ogm_bytes = (c.sensors & SMX_SENSOR_OGM) ? (size_t)c.ogm_width * c.ogm_height : 0;
   const bool ogm_inline = small_batch && ogm_bytes > 0 && ogm_bytes <= 16 * 1024;
   const bool ogm_alone = ogm_bytes > 0 && !ogm_inline;
+  const size_t dagm_bytes = (c.sensors & SMX_SENSOR_DAGM) ? (size_t)c.dagm_width * c.dagm_height : 0;
+  a.dagm_reach = h->dagm_reach;
   a.wp_blocks = wp_blocks;
   a.obs_blocks = obs_blocks;
   a.lidar_blocks = lidar_blocks;
@@ -2013,6 +2102,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
     if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
+    if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_OGM + 1], stream);
     if (small_batch) {
       hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, k);
@@ -2058,6 +2148,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_reset_env, dim3(env_blocks), dim3(SMX_BLOCK), 0, stream, r);
     }
     if (ogm_bytes) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, r);
+    if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, r);
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());

@@ -50,6 +50,10 @@ class SimConfig:
     ogm_width: int = 256
     ogm_height: int = 256
     ogm_resolution: float = 50 / 256
+    dagm: bool = False  # agent_interface.py:29-38 (DrivableAreaGridMap defaults 256 x 256 @ 50/256)
+    dagm_width: int = 256
+    dagm_height: int = 256
+    dagm_resolution: float = 50 / 256
     lidar: Optional[SensorParams] = None  # agent_interface.py:132-135
     # DoneCriteria.agents_alive (agent_interface.py:155-176): minima (None = unset) and up to four
     # (agent slots, minimum alive) lists
@@ -73,6 +77,8 @@ class SimConfig:
             m |= nat.SENSOR_OGM
         if self.lidar is not None:
             m |= nat.SENSOR_LIDAR
+        if self.dagm:
+            m |= nat.SENSOR_DAGM
         return m
 
     def done_mask(self) -> int:
@@ -251,6 +257,8 @@ class BatchedSim:
             c.ogm_width, c.ogm_height, c.ogm_resolution = cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution
         if cfg.lidar is not None:
             c.lidar_rays, c.lidar_max_distance = ray_count(cfg.lidar), cfg.lidar.max_distance
+        if cfg.dagm:
+            c.dagm_width, c.dagm_height, c.dagm_resolution = cfg.dagm_width, cfg.dagm_height, cfg.dagm_resolution
         self._c = c
         self.handle = C.c_void_p()
         rc = self.lib.smx_create(C.byref(c), idx, C.byref(self.handle))
@@ -356,6 +364,8 @@ class BatchedSim:
             o["via_hit"] = z((E, N), torch.int32)
         if cfg.ogm:
             o["ogm"] = z((E, N, cfg.ogm_height, cfg.ogm_width), torch.uint8)
+        if cfg.dagm:
+            o["dagm"] = z((E, N, cfg.dagm_height, cfg.dagm_width), torch.uint8)
         if cfg.lidar is not None:
             R = ray_count(cfg.lidar)
             o["lidar_hit"] = z((E, N, R), torch.uint8)
@@ -406,13 +416,14 @@ class BatchedSim:
             "waypoints": (3 * 8 + 4 + seeds + sum(v for k, v in o.items() if k.startswith("wp_"))) if self.cfg.waypoints else 0,
             # state + facts read, trip/accelerometer state written back, ego/neighbour/event/reward rows written
             "observe": state + facts + 12 * 8 + sum(
-                v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar"))),
+                v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar", "dagm"))),
         }
         ogm = (3 * 8 + 4 + o["ogm"]) if self.cfg.ogm else 0
+        dagm = (3 * 8 + 4 + o["dagm"]) if self.cfg.dagm else 0  # map segments are L2-resident, not counted
         ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
                       and self.E * self.N < 32768)  # smx_kernels.hip enqueue(): small batches only
-        if self.cfg.ogm and not ogm_inline:
-            kb["ogm"] = ogm  # its own launch
+        if (self.cfg.ogm and not ogm_inline) or self.cfg.dagm:
+            kb["ogm"] = (0 if ogm_inline else ogm) + dagm  # their own launches (one timing phase)
         lidar = (3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]) if self.cfg.lidar is not None else 0
         # k_sensors runs the waypoints, observe and lidar roles in one launch; k_commit applies the flags
         kb["sensors"] = kb.pop("waypoints") + kb.pop("observe") + lidar + (ogm if ogm_inline else 0)

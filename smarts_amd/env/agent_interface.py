@@ -225,12 +225,13 @@ class AgentInterface:
     def validate_for_device(self):
         """Raise for anything the MI355X path does not implement (the Lane,
         Continuous, ActuatorDynamic, LaneWithContinuousSpeed and Trajectory action spaces and the waypoints /
-        neighbourhood / accelerometer / OGM / lidar sensors)."""
-        if self.action not in DEVICE_ACTION_SPACES:
+        neighbourhood / accelerometer / OGM / drivable-area grid map / lidar sensors)."""
+        # action=None (AgentType.Buddha) needs no controller: the vehicle is never given a command
+        if self.action is not None and self.action not in DEVICE_ACTION_SPACES:
             raise NotImplementedError(
                 f"action space {self.action} is not on the accelerated path "
                 f"(supported: {[a.name for a in DEVICE_ACTION_SPACES]})")
-        for name in ("road_waypoints", "drivable_area_grid_map", "rgb"):
+        for name in ("road_waypoints", "rgb"):
             if getattr(self, name):
                 raise NotImplementedError(f"AgentInterface.{name} is not on the accelerated path")
         if self.vehicle_type != "sedan":

@@ -96,7 +96,7 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
         done_collision=dc.collision, done_off_road=dc.off_road, done_off_route=dc.off_route,
         done_on_shoulder=dc.on_shoulder, done_wrong_way=dc.wrong_way, done_not_moving=dc.not_moving,
         not_moving_time=evc.not_moving_time, not_moving_distance=evc.not_moving_distance, auto_reset=auto_reset,
-        action_space=itf.action.name,
+        action_space=itf.action.name if itf.action is not None else "Lane",  # None: every action is "no action"
     )
     alive = dc.agents_alive
     if alive is not None:
@@ -116,6 +116,9 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
         kw["wp_len"] = min(waypoint_window[1], itf.waypoints.lookahead + 1)
     if itf.ogm:
         kw.update(ogm=True, ogm_width=itf.ogm.width, ogm_height=itf.ogm.height, ogm_resolution=itf.ogm.resolution)
+    if itf.drivable_area_grid_map:
+        g = itf.drivable_area_grid_map
+        kw.update(dagm=True, dagm_width=g.width, dagm_height=g.height, dagm_resolution=g.resolution)
     if itf.lidar:
         kw.update(lidar=itf.lidar.sensor_params)
     return SimConfig(**kw)
@@ -162,7 +165,7 @@ class BatchCore:
         vehicle_names = self.agent_ids + [f"social-{k}" for k in range(num_social)]
         self.builder = ObservationBuilder(
             self.cm.lane_ids, road_ids, vehicle_names, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
-            accelerometer=self.cfg.accelerometer, ogm=first.ogm or None,
+            accelerometer=self.cfg.accelerometer, ogm=first.ogm or None, dagm=first.drivable_area_grid_map or None,
             lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias)
         self._was_reset = False
         self._destroyed = False
@@ -207,6 +210,8 @@ class BatchCore:
             for agent_id, action in agent_actions.items():
                 adapted = self.agent_specs[agent_id].action_adapter(action)
                 i = self.agent_ids.index(agent_id)
+                if adapted is None:
+                    continue  # count 0 = no action
                 packed[e, i], counts[e, i] = pack_trajectory(adapted)
         self._check_alive()
         if not self._was_reset:
@@ -217,7 +222,7 @@ class BatchCore:
 
     def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
         space = self.interface.action
-        lane = space is ActionSpaceType.Lane
+        lane = space is ActionSpaceType.Lane or space is None
         slots = self.N + self.num_social
         if lane:
             acts = np.full((self.E, slots), NO_ACTION, dtype=np.int8)
@@ -229,6 +234,10 @@ class BatchCore:
             for agent_id, action in agent_actions.items():
                 adapted = self.agent_specs[agent_id].action_adapter(action)
                 i = self.agent_ids.index(agent_id)
+                if adapted is None:
+                    continue  # controllers/__init__.py:90-91: no action, no control call this tick
+                if space is None:
+                    raise ValueError("perform_action(action_space=None, ...) has failed: the interface has no action space")
                 if lane:
                     acts[e, i] = encode_lane_action(adapted)
                 else:

@@ -134,7 +134,8 @@ def std_obs(obs: Observation) -> StdObs:
     """One ``Observation`` -> ``StdObs`` (format_obs.py:261-282)."""
     return StdObs(
         dist=np.float32(obs.distance_travelled), ego=_std_ego(obs.ego_vehicle_state), events=_std_events(obs.events),
-        dagm=None, lidar=_std_lidar(obs.lidar_point_cloud), neighbors=_std_neighbors(obs.neighborhood_vehicle_states),
+        dagm=obs.drivable_area_grid_map.data.astype(np.uint8) if obs.drivable_area_grid_map else None,
+        lidar=_std_lidar(obs.lidar_point_cloud), neighbors=_std_neighbors(obs.neighborhood_vehicle_states),
         ogm=obs.occupancy_grid_map.data.astype(np.uint8) if obs.occupancy_grid_map else None, rgb=None,
         ttc=_std_ttc(obs), waypoints=_std_waypoints(obs.waypoint_paths),
     )
@@ -208,9 +209,10 @@ class FormatObs:
             }
         if "ogm" in rows:
             ogm = np.array(rows["ogm"][env, slot], dtype=np.uint8)[..., None]
+        dagm = np.array(rows["dagm"][env, slot], dtype=np.uint8)[..., None] if "dagm" in rows else None
         if "lidar_hit" in rows:
             hit = rows["lidar_hit"][env, slot].astype(np.int8)
             cloud = np.nan_to_num(np.array(rows["lidar_point"][env, slot]), nan=0.0, posinf=0.0, neginf=0.0)
             lidar = {"hit": hit, "point_cloud": cloud}
         return StdObs(dist=np.float32(rows["dist"][env, slot]), ego=ego, events=events, lidar=lidar, neighbors=neighbors,
-                      ogm=ogm, waypoints=waypoints)
+                      ogm=ogm, waypoints=waypoints, dagm=dagm)

@@ -152,6 +152,13 @@ class GridMapMetadata(NamedTuple):
     camera_heading_in_degrees: float
 
 
+class DrivableAreaGridMap(NamedTuple):
+    """sensors.py:145-151."""
+
+    metadata: GridMapMetadata
+    data: np.ndarray
+
+
 class OccupancyGridMap(NamedTuple):
     """sensors.py:136-142."""
 
@@ -212,12 +219,13 @@ class ObservationBuilder:
 
     def __init__(self, lane_ids: Sequence[str], lane_road_ids: Sequence[str], agent_ids: Sequence[str], *,
                  waypoints: bool, neighbors: bool, accelerometer: bool, ogm=None, lidar_rays: Optional[np.ndarray] = None,
-                 dt: float = 0.1, vias=None):
+                 dt: float = 0.1, vias=None, dagm=None):
         self.lane_ids = list(lane_ids)
         self.lane_road_ids = list(lane_road_ids)
         self.agent_ids = list(agent_ids)
         self.waypoints, self.neighbors, self.accelerometer = waypoints, neighbors, accelerometer
         self.ogm, self.lidar_rays, self.dt = ogm, lidar_rays, dt
+        self.dagm = dagm
         self.vias = vias  # per vehicle slot: resolved mission vias (smarts_amd.vias.ResolvedVia)
 
     def vehicle_id(self, slot: int) -> str:
@@ -296,6 +304,13 @@ class ObservationBuilder:
                 height=self.ogm.height, camera_pos=tuple(float(x) for x in rows["ego_pos"][slot]),
                 camera_heading_in_degrees=float(np.degrees(float(f[E["HEADING"]]))))
             ogm = OccupancyGridMap(metadata=meta, data=np.array(rows["ogm"][slot], dtype=np.uint8)[..., None])
+        dagm = None
+        if self.dagm is not None:
+            meta = GridMapMetadata(
+                created_at=int(elapsed_sim_time), resolution=self.dagm.resolution, width=self.dagm.width,
+                height=self.dagm.height, camera_pos=tuple(float(x) for x in rows["ego_pos"][slot]),
+                camera_heading_in_degrees=float(np.degrees(float(f[E["HEADING"]]))))
+            dagm = DrivableAreaGridMap(metadata=meta, data=np.array(rows["dagm"][slot], dtype=np.uint8)[..., None])
         lidar = None
         if self.lidar_rays is not None:
             origin = np.array(rows["ego_pos"][slot], dtype=np.float64) + np.array([0.0, 0.0, 1.0])
@@ -318,5 +333,5 @@ class ObservationBuilder:
         return Observation(
             dt=self.dt, step_count=step_count, elapsed_sim_time=elapsed_sim_time, events=events, ego_vehicle_state=ego,
             neighborhood_vehicle_states=neighbors, waypoint_paths=paths, distance_travelled=float(rows["dist"][slot]),
-            lidar_point_cloud=lidar, drivable_area_grid_map=None, occupancy_grid_map=ogm, top_down_rgb=None,
+            lidar_point_cloud=lidar, drivable_area_grid_map=dagm, occupancy_grid_map=ogm, top_down_rgb=None,
             road_waypoints=None, via_data=via_data)

@@ -26,6 +26,7 @@ def oracle_config(cfg):
         alive_min_ego=cfg.alive_min_ego, alive_min_total=cfg.alive_min_total,
         alive_lists=tuple((tuple(s_), m) for s_, m in cfg.alive_lists),
         ogm=(cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution) if cfg.ogm else None,
+        dagm=(cfg.dagm_width, cfg.dagm_height, cfg.dagm_resolution) if cfg.dagm else None,
         lidar_rays=oracle_lidar_rays(cfg.lidar) if cfg.lidar is not None else None,
     )
 
@@ -62,6 +63,8 @@ def empty_dense(cfg, n):
                  via_hit=np.zeros(n, np.int32))
     if cfg.ogm:
         d["ogm"] = np.zeros((n, cfg.ogm_height, cfg.ogm_width), np.uint8)
+    if cfg.dagm:
+        d["dagm"] = np.zeros((n, cfg.dagm_height, cfg.dagm_width), np.uint8)
     if cfg.lidar is not None:
         from smarts_amd.lidar import ray_count
 
@@ -134,6 +137,8 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
             d["via_hit"][i] = sum(1 << k for k in hit)
         if cfg.ogm:
             d["ogm"][i] = o["ogm"]
+        if cfg.dagm:
+            d["dagm"][i] = o["dagm"]
         if cfg.lidar is not None:
             pts, hits = o["lidar"]
             d["lidar_hit"][i] = hits
@@ -142,7 +147,7 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
 
 
 INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
-            "nb_lane_id", "nb_slot", "nb_count", "ogm", "lidar_hit", "via_near", "via_near_count", "via_hit"]
+            "nb_lane_id", "nb_slot", "nb_count", "ogm", "dagm", "lidar_hit", "via_near", "via_near_count", "via_hit"]
 
 
 def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):

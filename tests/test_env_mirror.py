@@ -219,3 +219,10 @@ def test_make_mirrors_the_registered_id():
     e.close()
     with pytest.raises(ValueError):
         env_pkg.make("smarts.env:highway-v9", scenarios=["scenarios/loop"], agent_specs={"A": spec})
+
+
+def test_buddha_interface_is_accepted_without_an_action_space():
+    itf = AgentInterface.from_type(AgentType.Buddha)
+    itf.validate_for_device()
+    cfg = env_core.sim_config_from_interface(itf, 2, 3, 0.1, False)
+    assert cfg.action_space == "Lane" and not cfg.waypoints and not cfg.neighbors

@@ -238,3 +238,43 @@ def test_hiway_env_reports_mission_vias():
     d = [np.hypot(p.position[0] - pos[0], p.position[1] - pos[1]) for p in obs["A"].via_data.near_via_points]
     assert d == sorted(d) and obs["A"].via_data.near_via_points[0].road_id.startswith("edge-")
     env.close()
+
+
+def test_hiway_env_buddha_agent_sees_nothing_and_does_nothing():
+    """AgentType.Buddha (agent_interface.py:308-309): no sensors, no action space; ``None`` actions
+    reach no controller (controllers/__init__.py:90-91), so the vehicle just rolls on."""
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Buddha, max_episode_steps=8),
+                     agent_builder=lambda: Agent.from_function(lambda _: None))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={AGENT_ID: spec}, headless=True, seed=3)
+    obs = env.reset()
+    start = np.array(obs[AGENT_ID].ego_vehicle_state.position[:2])
+    assert not obs[AGENT_ID].waypoint_paths and not obs[AGENT_ID].neighborhood_vehicle_states
+    for _ in range(3):
+        obs, rewards, dones, _ = env.step({AGENT_ID: None})
+    moved = np.linalg.norm(np.array(obs[AGENT_ID].ego_vehicle_state.position[:2]) - start)
+    assert moved > 1.0 and obs[AGENT_ID].ego_vehicle_state.steering == pytest.approx(0.0, abs=1e-6)
+    with pytest.raises(ValueError):
+        env.step({AGENT_ID: "keep_lane"})  # an action without an action space fails in the controller dispatch
+    env.close()
+
+
+def test_hiway_env_drivable_area_grid_map_and_std_obs():
+    """AgentInterface.drivable_area_grid_map (agent_interface.py:29-38, 234-239) through the object API and
+    FormatObs' ``dagm`` key (format_obs.py:393-398)."""
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, DrivableAreaGridMap, FormatObs, HiWayEnv
+
+    itf = AgentInterface.from_type(AgentType.Laner, drivable_area_grid_map=DrivableAreaGridMap(64, 64, 50 / 64),
+                                   neighborhood_vehicles=True)
+    spec = AgentSpec(interface=itf, agent_builder=lambda: Agent.from_function(lambda _: "keep_lane"))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={AGENT_ID: spec}, headless=True, seed=11)
+    obs = env.reset()
+    grid = obs[AGENT_ID].drivable_area_grid_map
+    assert grid.data.shape == (64, 64, 1) and grid.data.dtype == np.uint8 and grid.metadata.resolution == 50 / 64
+    assert grid.data[30:34, 30:34].max() == 255 and grid.metadata.camera_pos == tuple(obs[AGENT_ID].ego_vehicle_state.position)
+    env.close()
+    wrapped = FormatObs(HiWayEnv(scenarios=["scenarios/loop"], agent_specs={AGENT_ID: spec}, headless=True, seed=11))
+    std = wrapped.reset()[AGENT_ID]
+    assert std.dagm.shape == (64, 64, 1) and np.array_equal(std.dagm, grid.data)
+    wrapped.close()

@@ -95,6 +95,37 @@ def test_ogm_and_lidar_sensors(name, E, N, T, seed, sensor, nets, compiled_maps)
     sim.close()
 
 
+@pytest.mark.parametrize("name,E,N,T,seed,grid", [("loop", 2, 8, 8, 35, (64, 64, 50 / 64)), ("4lane", 1, 12, 6, 36, (64, 32, 0.5)),
+                                                   ("minicity", 1, 6, 3, 37, None)])
+def test_drivable_area_grid_map(name, E, N, T, seed, grid, nets, compiled_maps):
+    """DrivableAreaGridMap (sensors.py:675-716; defaults 256 x 256 @ 50/256, agent_interface.py:29-38)
+    bit-exact against the oracle's raster, and the reference's own check (test_observations.py:150-153):
+    vehicles on the road sit on drivable pixels."""
+    import torch
+
+    from smarts_amd import _native as nat
+
+    kw = dict(dagm=True)
+    if grid is not None:
+        kw.update(dagm_width=grid[0], dagm_height=grid[1], dagm_resolution=grid[2])
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, **kw)
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(seed)
+    for t in range(T):
+        g = d["dagm"].reshape(E * N, cfg.dagm_height, cfg.dagm_width)
+        on_road = (d["active"].reshape(-1) != 0) & (d["events"][:, nat.EV_OFF_ROAD] == 0)
+        cy, cx = cfg.dagm_height // 2, cfg.dagm_width // 2
+        assert on_road.any() and (g[on_road, cy - 2:cy + 2, cx - 2:cx + 2].max(axis=(1, 2)) == 255).all()
+        assert 0 < (g[on_road] == 255).mean() < 1  # some road, not everything
+        acts = _actions(rng, E, N)
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{name} dagm t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+    sim.close()
+
+
 @pytest.mark.parametrize("space,name,E,N,T,seed", [("Continuous", "loop", 4, 8, 40, 41), ("ActuatorDynamic", "4lane", 2, 16, 30, 42),
                                                   ("LaneWithContinuousSpeed", "loop", 4, 8, 50, 43),
                                                   ("LaneWithContinuousSpeed", "minicity", 2, 16, 25, 44)])

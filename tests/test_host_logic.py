@@ -189,3 +189,29 @@ def test_compiled_map_cache_round_trip(tmp_path):
     other = load_compiled_map(str(d))
     assert other.extras["from_cache"] is False and other.n_lanes != ref.n_lanes
     assert build_scenario(str(d)).endswith(CACHE_NAME)
+
+
+def test_oracle_drivable_area_raster_properties(nets):
+    """oracle/sensors_extra.dagm: the reference's own check (test_observations.py:150-153: a vehicle on
+    the road is on a drivable pixel), plus rotation with the ego heading and the grid's extent."""
+    import math
+
+    from oracle.dynamics import VehicleBody
+    from oracle.road_network import ORoadNetwork
+    from oracle.sensors_extra import dagm
+
+    rmap = ORoadNetwork(nets("loop"))
+    shape = nets("loop").all_lanes()[0].getShape(False)
+    (x1, y1), (x2, y2) = shape[0], shape[1]
+    mx, my = 0.5 * (x1 + x2), 0.5 * (y1 + y2)
+    heading = math.atan2(y2 - y1, x2 - x1) - 0.5 * math.pi  # along the lane
+    g = dagm(VehicleBody(mx, my, heading, 0.0), rmap.lane_bands(), 64, 64, 50 / 64)
+    assert g.dtype == np.uint8 and g.shape == (64, 64) and set(np.unique(g)) == {0, 255}
+    assert g[30:34, 30:34].min() == 255  # on the centre line: drivable all round
+    # the lane runs "up" the image: the centre column is road where the lane is, columns far to the side are not
+    assert g[:, 32].mean() > g[:, 2].mean()
+    # same place, turned a quarter: the image turns with the vehicle
+    q = dagm(VehicleBody(mx, my, heading + 0.5 * math.pi, 0.0), rmap.lane_bands(), 64, 64, 50 / 64)
+    assert np.mean(np.rot90(g, -1) == q) > 0.97
+    # far from any road: nothing
+    assert dagm(VehicleBody(mx + 5000.0, my, 0.0, 0.0), rmap.lane_bands(), 32, 32, 1.0).max() == 0
