@@ -25,6 +25,7 @@ Pinning status (see DESIGN.md "Oracle"):
   unpinned** (the reference holds no golden poses and pybullet cannot run
   here) — the planar model in ``oracle/dynamics.py`` is a documented
   substitution.  Likewise **unpinned**: the OGM raster beyond the reference's
-  +-2 px check, lidar hits (ray / box instead of Bullet), and the scripted
+  +-2 px check, the drivable-area grid map likewise (lane bands instead of the rendered road
+  mesh), lidar hits (ray / box instead of Bullet), and the scripted
   social-traffic model that stands in for SUMO (``oracle/sim.py::SocialBody``).
 """
