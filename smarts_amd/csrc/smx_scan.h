@@ -7,7 +7,9 @@
 #pragma once
 #include "smx_roadmap.h"
 
+#ifndef SMX_TEAM
 #define SMX_TEAM 8
+#endif
 
 __device__ __forceinline__ int team_rank() { return threadIdx.x & (SMX_TEAM - 1); }
 
