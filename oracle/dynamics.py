@@ -51,6 +51,8 @@ TOTAL_MASS = 2356.0 + 4 * 15.0 + 2 * 1.0 + 1.0
 AXLE_DIST = 1.5  # both axles sit 1.5 m from the base frame
 TRACK_HALF = 0.5
 TOTAL_INERTIA_Z = CHASSIS_INERTIA_Z + (4 * 15.0 + 2 * 1.0) * (AXLE_DIST ** 2 + TRACK_HALF ** 2)
+INV_TOTAL_MASS = 1.0 / TOTAL_MASS
+INV_TOTAL_INERTIA_Z = 1.0 / TOTAL_INERTIA_Z
 WHEELBASE = 3.0
 REAR_AXLE_TO_BASE = 1.5
 CORNERING_STIFFNESS = 100000.0  # = ROAD_STIFFNESS, the controller's design value
@@ -180,12 +182,15 @@ class VehicleBody:
                 # a brake opposes motion; it does not push the car backwards
                 u_new = max(0.0, u_new - h * brake_decel)
             if u_new >= KINEMATIC_BELOW_SPEED:
-                alpha_f = self.delta - (v + AXLE_DIST * r) / u_new
-                alpha_r = -(v - AXLE_DIST * r) / u_new
+                # one reciprocal per substep and reciprocal constants: the model is this module's own
+                # (a substitution), and the device evaluates exactly this form
+                inv_u = 1.0 / u_new
+                alpha_f = self.delta - (v + AXLE_DIST * r) * inv_u
+                alpha_r = -(v - AXLE_DIST * r) * inv_u
                 f_f = min(max(CORNERING_STIFFNESS * alpha_f, -f_max), f_max)
                 f_r = min(max(CORNERING_STIFFNESS * alpha_r, -f_max), f_max)
-                v_new = v + h * ((f_f + f_r) / TOTAL_MASS - u_new * r)
-                r_new = r + h * (AXLE_DIST * (f_f - f_r) / TOTAL_INERTIA_Z)
+                v_new = v + h * ((f_f + f_r) * INV_TOTAL_MASS - u_new * r)
+                r_new = r + h * (AXLE_DIST * (f_f - f_r) * INV_TOTAL_INERTIA_Z)
             else:
                 r_new = u_new * math.tan(self.delta) / WHEELBASE
                 v_new = r_new * REAR_AXLE_TO_BASE

@@ -403,6 +403,7 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
   const double drive_accel = 4.0 * (c.throttle * SMX_MAX_TORQUE) / SMX_WHEEL_RADIUS / SMX_TOTAL_MASS;
   const double brake_decel = 4.0 * (brake * SMX_MAX_BTORQUE) / SMX_WHEEL_RADIUS / SMX_TOTAL_MASS;
   const double f_max = 0.5 * SMX_GROUND_FRICTION * SMX_TOTAL_MASS * SMX_GRAVITY;
+  const double inv_mass = 1.0 / SMX_TOTAL_MASS, inv_inertia = 1.0 / SMX_TOTAL_INERTIA_Z;
   for (int k = 0; k < substeps; ++k) {
     s.delta += SMX_STEER_POSITION_GAIN * (delta_target - s.delta);
     s.delta = fmin(fmax(s.delta, -SMX_STEER_LIMIT), SMX_STEER_LIMIT);
@@ -411,12 +412,14 @@ __device__ inline void vehicle_step(VehState& s, ControlOut c, double dt) {
     if (brake_decel > 0.0 && u_new > 0.0) u_new = fmax(0.0, u_new - h * brake_decel);
     double v_new, r_new;
     if (u_new >= SMX_KINEMATIC_BELOW_SPEED) {
-      double alpha_f = s.delta - (v + SMX_AXLE_DIST * r) / u_new;
-      double alpha_r = -(v - SMX_AXLE_DIST * r) / u_new;
+      // one reciprocal per substep, reciprocal constants (the form oracle/dynamics.py states)
+      const double inv_u = 1.0 / u_new;
+      double alpha_f = s.delta - (v + SMX_AXLE_DIST * r) * inv_u;
+      double alpha_r = -(v - SMX_AXLE_DIST * r) * inv_u;
       double f_f = fmin(fmax(SMX_CORNERING_STIFFNESS * alpha_f, -f_max), f_max);
       double f_r = fmin(fmax(SMX_CORNERING_STIFFNESS * alpha_r, -f_max), f_max);
-      v_new = v + h * ((f_f + f_r) / SMX_TOTAL_MASS - u_new * r);
-      r_new = r + h * (SMX_AXLE_DIST * (f_f - f_r) / SMX_TOTAL_INERTIA_Z);
+      v_new = v + h * ((f_f + f_r) * inv_mass - u_new * r);
+      r_new = r + h * (SMX_AXLE_DIST * (f_f - f_r) * inv_inertia);
     } else {
       r_new = u_new * tan(s.delta) / SMX_WHEELBASE;
       v_new = r_new * SMX_AXLE_DIST;
