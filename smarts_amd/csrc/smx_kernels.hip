@@ -193,10 +193,27 @@ __device__ __forceinline__ VehState load_vehicle(const KernelArgs& a, size_t gid
 
 // One instantiation per action space: the Lane kernel does not carry the registers of the others.
 // waves_per_eu(2): at most 256 registers, so that two wavefronts share a SIMD on large batches.
-template <int SPACE>
+// LDS_PATH (small batches, lane-following spaces): the candidate path is written to LDS as it is
+// synthesised and read back with fixed indices by the lane that runs the control law.  In registers a
+// put at a run-time index is a 17-way compare / select chain over every live element (~90
+// instructions per waypoint); the LDS copy costs 26 KB per workgroup, which would halve the
+// wavefronts per CU on large batches, so those keep the register form.
+template <int SPACE, bool LDS_PATH = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX_BLOCK) k_control(const KernelArgs a) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  __shared__ double path_lds[LDS_PATH ? 3 * SMX_CTRL_WPS * SMX_BLOCK : 1];
   int* knots = knot_scratch + threadIdx.x;
+  // element (waypoint i, component q) of this lane's path: consecutive lanes, consecutive words
+  auto path_put = [&](CtrlPath& p, int i, double x, double y, double h) {
+    if (LDS_PATH) {
+      double* q = path_lds + (size_t)(i * 3) * SMX_BLOCK + threadIdx.x;
+      q[0] = x;
+      q[SMX_BLOCK] = y;
+      q[2 * SMX_BLOCK] = h;
+    } else {
+      ctrl_path_put(p, i, x, y, h);
+    }
+  };
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -327,7 +344,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
               if (r4 == 0 && cnt == 0) {
                 path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
                                              SMX_CTRL_WPS, [&](int i, const WaypointOut& w) {
-                                               ctrl_path_put(path, i, w.x, w.y, w.heading);
+                                               path_put(path, i, w.x, w.y, w.heading);
                                                if (i == 0) {
                                                  fx = w.x;
                                                  fy = w.y;
@@ -398,7 +415,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
           if (j == want - goff0) {
             path.n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK,
                                          SMX_CTRL_WPS,
-                                         [&](int i, const WaypointOut& w) { ctrl_path_put(path, i, w.x, w.y, w.heading); });
+                                         [&](int i, const WaypointOut& w) { path_put(path, i, w.x, w.y, w.heading); });
             break;
           }
           equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0,
@@ -415,6 +432,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
       SMX_TSTAMP(tc3);
       SMX_TACC(17, tc2, tc3);
       if (p0 == act_lane) {
+        if (LDS_PATH) {
+#pragma unroll
+          for (int k = 0; k < SMX_CTRL_WPS; ++k) {
+            const double* q = path_lds + (size_t)(k * 3) * SMX_BLOCK + threadIdx.x;
+            const bool held = k < path.n;
+            path.x[k] = held ? q[0] : 0.0;
+            path.y[k] = held ? q[SMX_BLOCK] : 0.0;
+            path.h[k] = held ? q[2 * SMX_BLOCK] : 0.0;
+          }
+        }
         // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
         if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, path);
         co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
@@ -2115,10 +2142,15 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_COMMIT + 1], stream);
   };
+  // the LDS-path form of k_control fits one wavefront per SIMD: only while the batch needs no more
+  const bool lds_path = total * SMX_WP_LANES <= (size_t)1024 * 64;
   if (is_step) {
     switch (c.action_space) {
       case SMX_ACTION_SPACE_LANE:
-        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        if (lds_path)
+          hipLaunchKernelGGL((k_control<SMX_ACTION_SPACE_LANE, true>), dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
+        else
+          hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
         break;
       case SMX_ACTION_SPACE_CONTINUOUS:
         hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_CONTINUOUS>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
@@ -2127,8 +2159,12 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_ACTUATOR_DYNAMIC>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
         break;
       case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
-        hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0,
-                           stream, a);
+        if (lds_path)
+          hipLaunchKernelGGL((k_control<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED, true>), dim3(wp_blocks),
+                             dim3(SMX_BLOCK), 0, stream, a);
+        else
+          hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0,
+                             stream, a);
         break;
       default:
         hipLaunchKernelGGL(k_control<SMX_ACTION_SPACE_TRAJECTORY>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
