@@ -496,6 +496,8 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TSTAMP(ts0);
   const VehState s = load_vehicle(a, gid, total);
   int32_t* fi = a.st.facts_i32;
+  if ((a.debug_skip & 512) && role == 1) return;
+  if ((a.debug_skip & 1024) && role == 0) return;
   if (role == 0) {
     // ---- road facts
     const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
@@ -516,6 +518,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
     // nearest lane closest to the vehicle; junction lanes are exempt (:548-551)
     double lane_heading = 0.0;
+    if (a.debug_skip & 2048) return;
     const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
     if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
     SMX_TSTAMP(ts2);
@@ -538,13 +541,23 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TACC(12, ts3, ts4);
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   // what the controller (and the waypoints sensor) ask: paths at this pose with the agent's route
-  const PathSeeds seed = team_compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true, t);
+  if (a.debug_skip & 4096) return;
+  Top10Scores sc;
+  if (a.debug_skip & 256) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sc.rel[k] = 0.0;
+  } else {
+    sc = team_top10_heading_terms(m, t, s.heading);
+  }
+  SMX_TSTAMP(ts4b);
+  SMX_TACC(9, ts4, ts4b);
+  const PathSeeds seed = team_compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true, t, sc);
   // without the waypoints sensor the observation still takes the first waypoint of
   // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
   // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
   int obs_start = -1, trip_start = -1;
   if (!wp_on || (flags & SMX_F_FIRST)) {
-    const PathSeeds ts = team_compute_path_seeds(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t);
+    const PathSeeds ts = team_compute_path_seeds(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc);
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }

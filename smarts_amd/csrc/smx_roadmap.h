@@ -205,7 +205,24 @@ __device__ inline void nearest10(const MapDev& m, double px, double py, Top10& t
 // closest_lanepoints([pose], within_radius)[0] from the 10 nearest (lanepoints.py:526-590):
 // those beyond within_radius dropped (the nearest always kept), winner = min of
 // dist^2 + |heading difference| (first minimum in distance order).  within_radius < 0 = None.
-__device__ inline int pick_closest(const MapDev& m, const Top10& t, double heading, double within_radius) {
+// The heading term of every candidate, computed once for all the queries of a tick: the ten
+// lanepoint headings are loaded back to back (one scattered load per candidate behind the
+// candidate's own test would be ten load latencies in a row, per query).
+struct Top10Scores {
+  double rel[10];  // |heading difference| of candidate k
+};
+
+__device__ inline Top10Scores top10_heading_terms(const MapDev& m, const Top10& t, double heading) {
+  Top10Scores sc;
+  double h[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) h[k] = m.lp_rec[SMX_BCHK(12, t.idx[k] < 0 ? 0 : t.idx[k], m.n_lanepoints)].heading;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) sc.rel[k] = fabs(heading_relative_to(heading, h[k]));
+  return sc;
+}
+
+__device__ inline int pick_closest(const Top10& t, const Top10Scores& sc, double within_radius) {
   const double r2 = within_radius * within_radius;
   int best = -1;
   double best_score = SMX_INF;
@@ -213,13 +230,17 @@ __device__ inline int pick_closest(const MapDev& m, const Top10& t, double headi
   for (int k = 0; k < 10; ++k) {
     if (t.idx[k] < 0) continue;
     if (within_radius >= 0.0 && k > 0 && !(t.d2[k] <= r2)) continue;
-    double score = t.d2[k] + fabs(heading_relative_to(heading, m.lp_rec[SMX_BCHK(12, t.idx[k], m.n_lanepoints)].heading));
+    double score = t.d2[k] + sc.rel[k];
     if (score < best_score) {
       best_score = score;
       best = t.idx[k];
     }
   }
   return best;
+}
+
+__device__ inline int pick_closest(const MapDev& m, const Top10& t, double heading, double within_radius) {
+  return pick_closest(t, top10_heading_terms(m, t, heading), within_radius);
 }
 
 // closest_linked_lanepoint_on_lane_to_point (lanepoints.py:629-636) for up to 4 lanes at once

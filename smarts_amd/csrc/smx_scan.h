@@ -143,6 +143,45 @@ __device__ __forceinline__ void lp_ring_visit_team(const MapDev& m, int cx, int 
   }
 }
 
+// Rings 0..R around (cx, cy) in one go: the (2R+1) rows of the block are (2R+1) contiguous member
+// ranges, whose 2 (2R+1) offsets are loaded together before any member is touched.  Ring by ring
+// the same cells cost a dependent offset load per row segment (13 for R = 2) in front of their
+// members — with one wavefront per SIMD nothing hides that latency.  The order of the visit does
+// not matter to the callers (minima with an index tie-break).
+template <int R, class F>
+__device__ __forceinline__ void lp_block_visit_team(const MapDev& m, int cx, int cy, int rank, F&& f) {
+  constexpr int ROWS = 2 * R + 1;
+  int a[ROWS], b[ROWS];
+  const int xa = max(cx - R, 0), xb = min(cx + R, m.lpg_nx - 1);
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int y = cy - R + i;
+    const bool in = y >= 0 && y < m.lpg_ny && xa <= xb;
+    const int row = (in ? y : 0) * m.lpg_nx;
+    const int va = m.lpg_off[in ? row + xa : 0], vb = m.lpg_off[in ? row + xb + 1 : 0];
+    a[i] = va;
+    b[i] = in ? vb : va;
+  }
+  // step j takes this lane's j-th member of EVERY row: the ROWS records are loaded back to back
+  // (independent addresses) and only then looked at, instead of one load -> wait -> use per member
+  for (int j = 0;; ++j) {
+    smx_pt_rec rec[ROWS];
+    bool ok[ROWS];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int k = a[i] + rank + j * SMX_TEAM;
+      ok[i] = k < b[i];
+      any = any || ok[i];
+      rec[i] = m.lpg_pts[ok[i] ? k : 0];
+    }
+    if (!any) break;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+      if (ok[i]) f(rec[i]);
+  }
+}
+
 // The 10 nearest lanepoints (see nearest10).  Each lane keeps the best 10 of its share; the team
 // merges by repeatedly taking the smallest head.  Every lane ends with the same Top10.
 __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top10& res) {
@@ -159,29 +198,36 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
   const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
   const int keff = min(K, m.n_lanepoints);
   const int rmax = lp_max_ring(m, cx, cy);
+  // `bound`: the merged 10th smallest distance so far (SMX_INF before the first merge).  A point
+  // beyond it cannot be one of the 10 nearest, so it is not worth the insertion chain.
+  double bound = SMX_INF;
+  auto take = [&](const smx_pt_rec& p) {
+    double dx = p.x - px, dy = p.y - py;
+    double d2 = dx * dx + dy * dy;
+    if (d2 <= bound && (d2 < ld[K - 1] || (d2 == ld[K - 1] && p.idx < li[K - 1]))) {
+      double cd = d2;
+      int ci = p.idx;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        bool lt = (cd < ld[k]) || (cd == ld[k] && ci < li[k]);
+        double td = lt ? ld[k] : cd;
+        int ti = lt ? li[k] : ci;
+        ld[k] = lt ? cd : ld[k];
+        li[k] = lt ? ci : li[k];
+        cd = td;
+        ci = ti;
+      }
+    }
+  };
   int r = 0;
   for (;;) {
-    // two rings per merge: with 4 m cells the 10th neighbour is usually inside ring 2
-    const int r_end = min(rmax, r + (r == 0 ? 2 : 0));
-    for (; r <= r_end; ++r) {
-      lp_ring_visit_team(m, cx, cy, r, rank, [&](const smx_pt_rec& p) {
-        double dx = p.x - px, dy = p.y - py;
-        double d2 = dx * dx + dy * dy;
-        if (d2 < ld[K - 1] || (d2 == ld[K - 1] && p.idx < li[K - 1])) {
-          double cd = d2;
-          int ci = p.idx;
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            bool lt = (cd < ld[k]) || (cd == ld[k] && ci < li[k]);
-            double td = lt ? ld[k] : cd;
-            int ti = lt ? li[k] : ci;
-            ld[k] = lt ? cd : ld[k];
-            li[k] = lt ? ci : li[k];
-            cd = td;
-            ci = ti;
-          }
-        }
-      });
+    if (r == 0) {
+      // rings 0-2 before the first merge: with 4 m cells the 10th neighbour is usually inside ring 2
+      lp_block_visit_team<2>(m, cx, cy, rank, take);
+      r = 3;
+    } else {
+      lp_ring_visit_team(m, cx, cy, r, rank, take);
+      ++r;
     }
     // merge (on copies: the local lists keep growing if another ring is needed)
     double hd[K];
@@ -209,6 +255,7 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
         hi[K - 1] = 0x7fffffff;
       }
     }
+    bound = fmin(bound, res.d2[K - 1]);  // SMX_INF while fewer than 10 points have been seen
     const int last = r - 1;  // last completed ring
     bool full = false;
 #pragma unroll
@@ -229,21 +276,26 @@ __device__ inline void team_closest_filtered4(const MapDev& m, double px, double
   const int rmax = lp_max_ring(m, cx, cy);
   double rd[4];
   int ri[4];
-  for (int r = 0; r <= rmax; ++r) {
-    lp_ring_visit_team(m, cx, cy, r, rank, [&](const smx_pt_rec& p) {
-      const int key = by_road ? m.lane_road[p.lane] : p.lane;
-      double dx = p.x - px, dy = p.y - py;
-      double d2 = dx * dx + dy * dy;
+  auto take = [&](const smx_pt_rec& p) {
+    const int key = by_road ? m.lane_road[p.lane] : p.lane;
+    double dx = p.x - px, dy = p.y - py;
+    double d2 = dx * dx + dy * dy;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
-        if (q < nkeys && key == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
-          bd[q] = d2;
-          bi[q] = p.idx;
-        }
+    for (int q = 0; q < 4; ++q) {
+      const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+      if (q < nkeys && key == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+        bd[q] = d2;
+        bi[q] = p.idx;
       }
-    });
-    if (r < 1) continue;  // ring 0 alone never certifies
+    }
+  };
+  // rings 0-2 at once (the lanes of a road lie up to ~3 lane widths away: ring 1 seldom certifies
+  // them all), then ring by ring; a certified minimum is the global one whichever ring certifies it
+  for (int r = 2; r <= max(rmax, 2); ++r) {
+    if (r == 2)
+      lp_block_visit_team<2>(m, cx, cy, rank, take);
+    else
+      lp_ring_visit_team(m, cx, cy, r, rank, take);
     bool all = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -266,9 +318,32 @@ __device__ inline void team_closest_filtered4(const MapDev& m, double px, double
   }
 }
 
+// top10_heading_terms over the team: lane r evaluates candidates r, r + SMX_TEAM, ...; every lane
+// receives all ten by shuffles.
+__device__ inline Top10Scores team_top10_heading_terms(const MapDev& m, const Top10& t, double heading) {
+  const int rank = team_rank();
+  constexpr int PER = (10 + SMX_TEAM - 1) / SMX_TEAM;
+  double mine[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int k = rank + j * SMX_TEAM;
+    int idx = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+      if (q == k) idx = t.idx[q];
+    const double h = m.lp_rec[idx < 0 ? 0 : idx].heading;
+    mine[j] = fabs(heading_relative_to(heading, h));
+  }
+  Top10Scores sc;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) sc.rel[k] = __shfl(mine[k / SMX_TEAM], k % SMX_TEAM, SMX_TEAM);
+  return sc;
+}
+
 // compute_path_seeds, team form (see smx_roadmap.h for the semantics)
 __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
-                                                    double within_radius, bool has_route_object, const Top10& t) {
+                                                    double within_radius, bool has_route_object, const Top10& t,
+                                                    const Top10Scores& sc) {
   PathSeeds s;
   s.f.n = 0;
   s.f.road[0] = s.f.road[1] = -1;
@@ -277,8 +352,9 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
 #pragma unroll
   for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
   bool routed = false;
+  SMX_TSTAMP(tp0);
   if (has_route_object) {
-    int lp = pick_closest(m, t, heading, -1.0);
+    int lp = pick_closest(t, sc, -1.0);
     if (lp >= 0) {
       int road = m.lane_road[m.lp_rec[lp].lane];
       if (m.road_is_junction[road]) {
@@ -307,16 +383,22 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
     }
   }
   if (!routed) {
-    int lp = pick_closest(m, t, heading, within_radius);
+    int lp = pick_closest(t, sc, within_radius);
     s.road = lp >= 0 ? m.lane_road[m.lp_rec[lp].lane] : -1;
   }
+  SMX_TSTAMP(tp1);
+  SMX_TACC(21, tp0, tp1);
   if (s.road >= 0) {
     const int la = m.road_lane_off[s.road], lb = m.road_lane_off[s.road + 1];
     s.n_lanes = lb - la;
     const int nk = min(s.n_lanes, SMX_SEED_LANES);
     const int k0 = m.road_lanes[la], k1 = nk > 1 ? m.road_lanes[la + 1] : -9, k2 = nk > 2 ? m.road_lanes[la + 2] : -9,
               k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
+    SMX_TSTAMP(tp2);
+    SMX_TACC(22, tp1, tp2);
     team_closest_filtered4(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
+    SMX_TSTAMP(tp3);
+    SMX_TACC(23, tp2, tp3);
   }
   return s;
 }

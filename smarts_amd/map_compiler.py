@@ -274,6 +274,10 @@ def _csr(lists, n_cells):
 
 def compile_map(net: SumoNet, lanepoint_spacing: float = 1.0, default_lane_width: float = 3.2,
                 lp_cell: float = 4.0, seg_cell: float = 8.0) -> CompiledMap:
+    import os
+
+    lp_cell = float(os.environ.get("SMX_DEV_LP_CELL", lp_cell))  # developer experiments only
+    seg_cell = float(os.environ.get("SMX_DEV_SEG_CELL", seg_cell))
     lanes = net.all_lanes()
     lane_no = {l.getID(): i for i, l in enumerate(lanes)}
     edges = net.getEdges(True)

@@ -17,10 +17,10 @@ torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 24)(); lib.smx_prof_read(b
 T = 50
 for _ in range(T): sim.step(acts)
 torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
-names = {0: 'wp: loads+seeds', 1: 'wp: paths (walk+emit)', 3: 'wp: total (lane-0 waves)', 4: 'esp pass1 (all callers)', 5: 'esp pass2 (all callers)', 6: 'observe: total', 7: 'observe: loads+barrier', 8: 'observe: collide+ego+nb',
-         10: 'scan: road facts (8 lanes/veh)', 11: 'scan: lane heading', 12: 'scan: nearest10', 13: 'scan: path seeds', 14: 'scan: total',
+names = {9: 'seeds: heading terms of the 10 nearest', 0: 'wp: loads+seeds', 1: 'wp: paths (walk+emit)', 3: 'wp: total (lane-0 waves)', 4: 'esp pass1 (all callers)', 5: 'esp pass2 (all callers)', 6: 'observe: total', 7: 'observe: loads+barrier', 8: 'observe: collide+ego+nb',
+         10: 'scan: road facts (8 lanes/veh)', 11: 'scan: lane heading', 12: 'scan: nearest10', 13: 'scan: path seeds', 14: 'scan: total', 21: 'seeds: pick_closest (+junction case)', 22: 'seeds: road -> lanes loads', 23: 'seeds: closest lanepoint per lane',
          15: 'control: loads', 16: 'control: path walk+synth', 17: 'control: reduce+shuffle', 18: 'control: law (lane 0)', 19: 'control: physics', 20: 'control: total (lane-0 waves)'}
-lanes = {0: 4, 1: 4, 3: 4, 4: 4, 5: 4, 6: 1, 7: 1, 8: 1, 10: 8, 11: 8, 12: 8, 13: 8, 14: 8, 15: 4, 16: 4, 17: 4, 18: 4, 19: 4, 20: 4}
+lanes = {9: 8, 0: 4, 1: 4, 3: 4, 4: 4, 5: 4, 6: 1, 7: 1, 8: 1, 10: 8, 11: 8, 12: 8, 13: 8, 14: 8, 21: 8, 22: 8, 23: 8, 15: 4, 16: 4, 17: 4, 18: 4, 19: 4, 20: 4}
 for k in sorted(names):
     waves = (E * N * lanes[k] + 63) // 64
     print(f'{names[k]:36s} {buf[k] / T / waves / 100.0:10.2f} us/wave (100 MHz clock)')
