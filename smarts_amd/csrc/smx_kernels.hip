@@ -572,9 +572,16 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TACC(14, ts0, ts6);
 }
 
-// the back-to-back form only runs on large batches: one more wavefront per SIMD is worth 17 spills
+// Register budgets (amdgpu_waves_per_eu): the split form runs on small batches, where at most two or
+// three wavefronts per SIMD exist anyway, and takes the ~160 registers it wants — capped at 128 it
+// spilled 136 B per lane and cost 10 us of 48 at 8 k vehicles, plus 9 MB of scratch write-back per
+// tick.  The back-to-back form (large batches) is capped at 128 registers: four wavefronts per
+// SIMD; five (96 registers, 276 B of spills) was 1.5x slower at 131 k vehicles.
+#ifndef SMX_SCAN_WAVES
+#define SMX_SCAN_WAVES 4
+#endif
 template <bool SPLIT>
-__global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 5, 8))) __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8))) __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -632,6 +639,10 @@ __device__ __forceinline__ WpRows wp_rows(const smx_outputs& o, size_t gid, int 
 }
 
 __device__ __forceinline__ void wp_put(const MapDev& m, WpRows& r, int i, const WaypointOut& w) {
+  if (r.pos == nullptr) {  // developer switch (SMX_DEBUG_SKIP & 32768): compute, do not store
+    if (i == 0x7fffffff) r.cached_index = (int)(w.x + w.y + w.heading + w.width + w.speed) + w.lane;
+    return;
+  }
   if (w.lane != r.cached_lane) {
     r.cached_lane = w.lane;
     r.cached_index = m.lane_index[w.lane];
@@ -647,6 +658,7 @@ __device__ __forceinline__ void wp_put(const MapDev& m, WpRows& r, int i, const 
 }
 
 __device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
+  if (r.pos == nullptr) return;
   for (int i = from; i < W; ++i) {
     r.pos[i * 3 + 0] = 0.0;
     r.pos[i * 3 + 1] = 0.0;
@@ -668,6 +680,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
+  if (a.debug_skip & 16384) return;
   SMX_TSTAMP(tw0);
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
@@ -714,6 +727,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         do {
           if (cnt == 0 && prov < P) {
             WpRows rows = wp_rows(o, gid, P, W, prov);
+            if (a.debug_skip & 32768) rows.pos = nullptr;
             const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, W,
                                               [&](int i, const WaypointOut& w) {
                                                 if (i == 0) {
@@ -963,6 +977,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
   const SharedPose* env_pose = pose + env_local * n_veh;
 
+  if (a.debug_skip & 8192) return;
   SMX_TSTAMP(to0);
   VehState s = {0, 0, 0, 0, 0, 0, 0};
   int flags = 0;
