@@ -671,9 +671,9 @@ __device__ __forceinline__ void wp_zero(const WpRows& r, int from, int W) {
   }
 }
 
-__device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t gid) {
-  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
-  int* knots = knot_scratch + threadIdx.x;
+// `knots`: this thread's column of a [SMX_MAX_KNOTS][KSTRIDE] LDS scratch owned by the kernel
+template <int KSTRIDE>
+__device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t gid, int* knots) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
@@ -699,7 +699,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
       bs.reset();
       RouteFilter nof;
       nof.n = 0;
-      equally_spaced_path(m, nof, bs, os, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+      equally_spaced_path(m, nof, bs, os, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
         have_first_wp = true;
         fwx = w.x;
         fwy = w.y;
@@ -728,7 +728,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
           if (cnt == 0 && prov < P) {
             WpRows rows = wp_rows(o, gid, P, W, prov);
             if (a.debug_skip & 32768) rows.pos = nullptr;
-            const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, W,
+            const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, W,
                                               [&](int i, const WaypointOut& w) {
                                                 if (i == 0) {
                                                   gx = w.x;
@@ -740,7 +740,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
             wp_zero(rows, n < W ? n : W, W);
             o.wp_count[gid * (P + 1) + 1 + prov] = (uint8_t)(n < W ? n : W);
           } else {
-            equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, 0,
+            equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, 0,
                                 [&](int, const WaypointOut&) {});
           }
           ++cnt;
@@ -771,7 +771,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
             const bool first_path = (idx == 0 && p0 == 0);
             if (kept || first_path) {
               WpRows rows = wp_rows(o, gid, P, W, kept ? idx : 0);
-              const int n = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, SMX_BLOCK, kept ? W : 1,
+              const int n = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, KSTRIDE, kept ? W : 1,
                                                 [&](int i, const WaypointOut& w) {
                                                   if (first_path && i == 0) {
                                                     have_first_wp = true;
@@ -786,7 +786,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
                 o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
               }
             } else if (p0 == 0 || idx < P) {
-              equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, SMX_BLOCK, 0,
+              equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, KSTRIDE, 0,
                                   [&](int, const WaypointOut&) {});
             }
             ++idx;
@@ -819,7 +819,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
       bs.reset();
       RouteFilter nof;
       nof.n = 0;
-      equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, SMX_BLOCK, 1, [&](int, const WaypointOut& w) {
+      equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
         SF(SMX_S_TRIP_X) = w.x;
         SF(SMX_S_TRIP_Y) = w.y;
         SF(SMX_S_TRIP_H) = w.heading;
@@ -863,7 +863,8 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
 }
 
 __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int block) {
-  waypoints_for(a, ((size_t)block * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES);
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  waypoints_for<SMX_BLOCK>(a, ((size_t)block * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, knot_scratch + threadIdx.x);
 }
 
 // =================================================================================
@@ -996,7 +997,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   }
   const HeadingTrig trig = heading_trig(s.heading);
   const double speed = vehicle_speed(s, trig);
-  {
+  if (local < SMX_BLOCK) {  // k_first runs this role in a wider workgroup: the extra threads hold nothing
     SharedPose& p = pose[local];
     p.x = s.x;
     p.y = s.y;
@@ -1332,8 +1333,10 @@ __device__ __forceinline__ void commit_role(const KernelArgs& a, const int block
   const bool valid = (env_local < epb) && (env < c.num_envs);
   const size_t total = (size_t)c.num_envs * n_veh;
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
-  env_new_done[local] = 0;
-  env_respawn[local] = 0;
+  if (local < SMX_BLOCK) {
+    env_new_done[local] = 0;
+    env_respawn[local] = 0;
+  }
   __syncthreads();
   if (valid) {
     const int old_flags = a.st.flags[gid];
@@ -1357,7 +1360,7 @@ __device__ __forceinline__ void commit_role(const KernelArgs& a, const int block
     }
   }
   __syncthreads();
-  const bool respawn = valid && env_respawn[env_local] != 0;
+  const bool respawn = valid && env_respawn[valid ? env_local : 0] != 0;
   int next_episode = 0;
   if (respawn) {
     next_episode = a.st.env_episode[env] + 1;
@@ -1559,7 +1562,7 @@ __device__ __forceinline__ void lidar_role(const KernelArgs& a, const int block)
   const double ox = SF(SMX_S_X), oy = SF(SMX_S_Y), oz = SMX_BASE_HEIGHT + 1.0;
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH, hh = 0.5 * SMX_CHASSIS_HEIGHT;
   const double bz = SMX_BASE_HEIGHT + 0.6;  // chassis box centre height (models/vehicle.urdf)
-  for (int i = threadIdx.x; i < c.lidar_rays; i += SMX_BLOCK) {
+  for (int i = threadIdx.x; i < c.lidar_rays; i += (int)blockDim.x) {
     const double dx = a.lidar_rays[i * 3 + 0], dy = a.lidar_rays[i * 3 + 1], dz = a.lidar_rays[i * 3 + 2];
     double best = SMX_INF;
     if (dz < 0.0) {
@@ -1648,11 +1651,13 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
 // auto-reset tick pays for one empty launch instead of three.  (OGM tiles need dynamic LDS and keep
 // their own launch.)
 // =================================================================================
-__global__ void __launch_bounds__(SMX_BLOCK) k_first(const KernelArgs a) {
+#define SMX_FIRST_BLOCK 256
+__global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_FIRST_BLOCK];
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const int n_veh = c.num_vehicles;
-  const int epb = SMX_BLOCK / n_veh;
+  const int epb = SMX_BLOCK / n_veh;  // the env groups are those of the observe / commit roles
   const int block = (int)blockIdx.x;
   const size_t total = (size_t)c.num_envs * n_veh;
   const size_t g0 = (size_t)block * epb * n_veh;
@@ -1663,23 +1668,28 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_first(const KernelArgs a) {
     mine_first = (f & SMX_F_ALIVE) && (f & SMX_F_FIRST);
   }
   if (!__syncthreads_or(mine_first)) return;
-  // ---- scan: SMX_TEAM lanes per vehicle, both halves
-  for (size_t base = g0; base < g1; base += SMX_BLOCK / SMX_TEAM) {
-    const size_t gid = base + threadIdx.x / SMX_TEAM;
-    if (gid < g1) {
-      const int flags = a.st.flags[gid];
-      if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) {
-        scan_role(a, m, c, gid, total, team_rank(), flags, 0);
-        scan_role(a, m, c, gid, total, team_rank(), flags, 1);
+  // The workgroup is four wavefronts wide: a restarted env's chain scan -> sensors -> commit is
+  // pure latency, so its independent pieces run side by side — (vehicle, scan half) pairs over the
+  // teams of all four wavefronts, then the vehicles' waypoint teams — instead of one after the
+  // other in a single wavefront (an env of 16 vehicles: 4 scan rounds of ~40 us became 1).
+  // ---- scan: one team per (vehicle, half)
+  {
+    const size_t pairs = (g1 - g0) * 2;
+    for (size_t p0 = 0; p0 < pairs; p0 += SMX_FIRST_BLOCK / SMX_TEAM) {
+      const size_t pr = p0 + threadIdx.x / SMX_TEAM;
+      if (pr < pairs) {
+        const size_t gid = g0 + (pr >> 1);
+        const int flags = a.st.flags[gid];
+        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role(a, m, c, gid, total, team_rank(), flags, (int)(pr & 1));
       }
     }
   }
   __threadfence();
   __syncthreads();
   // ---- sensors
-  for (size_t base = g0; base < g1; base += SMX_BLOCK / SMX_WP_LANES) {
+  for (size_t base = g0; base < g1; base += SMX_FIRST_BLOCK / SMX_WP_LANES) {
     const size_t gid = base + threadIdx.x / SMX_WP_LANES;
-    if (gid < g1) waypoints_for(a, gid);
+    if (gid < g1) waypoints_for<SMX_FIRST_BLOCK>(a, gid, knot_scratch + threadIdx.x);
   }
   observe_role(a, block);
   if (c.sensors & SMX_SENSOR_LIDAR)
@@ -2213,7 +2223,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     }
     if (ogm_bytes) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, r);
     if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, r);
-    hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, r);
+    hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
   if (phased) {
