@@ -172,8 +172,9 @@ def cpu_baseline(net, cm, cfg_kw, args, seconds_budget=15.0):
 
 
 def copy_peak_gbps(device, torch):
-    """Measured device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer: the
-    practical HBM ceiling on this box, quoted beside the datasheet peak."""
+    """Measured device-to-device copy rate (read + write bytes / time) and fill rate (write bytes /
+    time) of a 1 GiB buffer: the practical HBM ceilings on this box, quoted beside the datasheet
+    peak."""
     n = 1 << 30
     src = torch.empty(n, dtype=torch.uint8, device=device)
     dst = torch.empty_like(src)
@@ -185,8 +186,18 @@ def copy_peak_gbps(device, torch):
         dst.copy_(src)
     b.record()
     torch.cuda.synchronize()
+    copy = 2.0 * n * 10 / (a.elapsed_time(b) * 1e-3) / 1e9
+    # write-only stream (the path is write-dominated: dense observation rows)
+    for _ in range(3):
+        dst.zero_()
+    a.record()
+    for _ in range(10):
+        dst.zero_()
+    b.record()
+    torch.cuda.synchronize()
+    fill = 1.0 * n * 10 / (a.elapsed_time(b) * 1e-3) / 1e9
     del src, dst
-    return 2.0 * n * 10 / (a.elapsed_time(b) * 1e-3) / 1e9
+    return copy, fill
 
 
 def main():
@@ -276,7 +287,7 @@ def main():
         phase_ms = sim.read_phase_ms().mean(axis=0)
         sim.set_timing(0)
 
-    copy_peak = copy_peak_gbps(device, torch) if rank == 0 else None
+    copy_peak, fill_peak = copy_peak_gbps(device, torch) if rank == 0 else (None, None)
     if rank == 0:
         total_envs = E * world
         env_steps_per_s = total_envs * args.steps / elapsed
@@ -337,6 +348,7 @@ def main():
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "measured_copy_peak": copy_peak,
+                "measured_fill_peak": fill_peak,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
