@@ -82,6 +82,8 @@ enum {
   SMX_SENSOR_DAGM = 1 << 5   /* drivable-area grid map (sensors.py:675-716) */
 };
 
+enum { SMX_SOCIAL_CONSTANT = 0, SMX_SOCIAL_IDM = 1 };
+
 /* ActionSpaceType (controllers/__init__.py:42-57) values on this path.  Lane takes int8 codes
  * (smx_step); the others take three floats per agent (smx_step_continuous):
  *   CONTINUOUS                 throttle, brake, steering                  (:94-99)
@@ -142,6 +144,14 @@ typedef struct smx_config {
    * row 0 ahead), 255 where the pixel centre lies within half a lane width of a lane centre line */
   int32_t dagm_width, dagm_height;
   double dagm_resolution;
+  /* Speed model of the scripted social vehicles: SMX_SOCIAL_CONSTANT = social_speed_factor x the speed
+   * limit; SMX_SOCIAL_IDM = intelligent-driver car following towards that desired speed (accel 2.6,
+   * decel 4.5, tau 1.0, min gap 2.5: SUMO's passenger defaults).  The leader is the nearest alive
+   * vehicle of the env (agents included) less than 60 m ahead along the follower's heading and less
+   * than 1.6 m to its side, read at the start of the tick; gap = centre distance - 3.68.  Parity with
+   * SUMO's own car-following is unpinned. */
+  int32_t social_model;
+  int32_t pad_social;
 } smx_config;
 
 /* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */

@@ -27,5 +27,6 @@ Pinning status (see DESIGN.md "Oracle"):
   substitution.  Likewise **unpinned**: the OGM raster beyond the reference's
   +-2 px check, the drivable-area grid map likewise (lane bands instead of the rendered road
   mesh), lidar hits (ray / box instead of Bullet), and the scripted
-  social-traffic model that stands in for SUMO (``oracle/sim.py::SocialBody``).
+  social-traffic models (constant speed, IDM car following) that stand in for SUMO
+  (``oracle/sim.py::SocialBody``).
 """

@@ -30,6 +30,7 @@ from . import sensors_extra as sx
 from .dynamics import VehicleBody
 
 COLLISION_LEEWAY = 0.05  # chassis.py:75-78
+CHASSIS_LENGTH = 3.68  # vehicle.py:101 (passenger)
 
 
 @dataclass
@@ -149,6 +150,7 @@ class SocialBody(VehicleBody):
     def __init__(self, x, y, heading, speed, lane, offset, slot, factor):
         super().__init__(x, y, heading, speed)
         self.lane, self.offset, self.slot, self.factor, self.crossed = lane, float(offset), slot, factor, 0
+        self.speed_cmd = None  # set every tick by the IDM model; None = constant fraction of the limit
 
     @staticmethod
     def _cum(lane):
@@ -162,8 +164,41 @@ class SocialBody(VehicleBody):
     def control(self, *a, **k):
         pass
 
+    # IDM car following (include/smx.h SMX_SOCIAL_IDM; SUMO's passenger defaults accel 2.6, decel 4.5,
+    # tau 1.0, minGap 2.5 — the arithmetic below is this project's own statement of the model)
+    IDM_ACCEL, IDM_DECEL, IDM_TAU, IDM_MIN_GAP = 2.6, 4.5, 1.0, 2.5
+    IDM_HORIZON, IDM_CORRIDOR = 60.0, 1.6
+
+    def idm_speed(self, others, dt):
+        """Speed for the coming tick from the poses / speeds at the start of the tick.
+        ``others``: (slot, body) of every other alive vehicle, in slot order."""
+        v = self.u
+        v0 = self.lane.speed_limit * self.factor
+        fx, fy = -math.sin(self.heading), math.cos(self.heading)
+        rx, ry = math.cos(self.heading), math.sin(self.heading)
+        best, lead_u, found = self.IDM_HORIZON, 0.0, False
+        for _, b in others:
+            dx, dy = b.x - self.x, b.y - self.y
+            lon = dx * fx + dy * fy
+            lat = dx * rx + dy * ry
+            if lon > 0.0 and lon < best and abs(lat) < self.IDM_CORRIDOR:
+                best, lead_u, found = lon, b.u, True
+        if v0 <= 0.0:
+            return max(0.0, v - self.IDM_DECEL * dt)
+        ratio = v / v0
+        free = 1.0 - (ratio * ratio) * (ratio * ratio)
+        inter = 0.0
+        if found:
+            gap = max(best - CHASSIS_LENGTH, 0.1)
+            dv = v - lead_u
+            sstar = self.IDM_MIN_GAP + max(0.0, v * self.IDM_TAU + v * dv / (2.0 * math.sqrt(self.IDM_ACCEL * self.IDM_DECEL)))
+            q = sstar / gap
+            inter = q * q
+        acc = self.IDM_ACCEL * (free - inter)
+        return min(max(v + acc * dt, 0.0), v0)
+
     def step(self, dt):
-        speed = self.lane.speed_limit * self.factor
+        speed = self.lane.speed_limit * self.factor if self.speed_cmd is None else self.speed_cmd
         self.offset += speed * dt
         for _ in range(64):
             L = self._cum(self.lane)[-1]
@@ -208,7 +243,8 @@ class _Social:
 class OracleEnv:
     """One SMARTS instance with N ego agents (and optional scripted social vehicles) on one map."""
 
-    def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8, vias=None):
+    def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8, vias=None,
+                 social_model="constant"):
         """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre) for the agents followed
         by the social vehicles; ``social``: (lane id, arclength offset) per social vehicle."""
         self.road_map = road_map
@@ -232,6 +268,7 @@ class OracleEnv:
             _Social(SocialBody(*spawns[n_agents + k], road_map.lane_by_id(lane_id), off, n_agents + k, social_speed_factor))
             for k, (lane_id, off) in enumerate(social)
         ]
+        self.social_model = social_model
 
     def _vehicles(self):
         """(slot, body) of every vehicle in the world, agents first (the vehicle-index order)."""
@@ -253,6 +290,14 @@ class OracleEnv:
         """``actions[i]`` is a Lane action name (or index into LANE_ACTION_NAMES) or None."""
         rmap = self.road_map
         self.elapsed_sim_time = round(self.elapsed_sim_time + self.dt, self._round)  # smarts.py:261-262
+        if self.social_model == "idm":
+            # every social vehicle decides from the state at the start of the tick
+            everyone = self._vehicles()
+            n_agents = len(self.agents)
+            cmds = [sv.body.idm_speed([(j, b) for j, b in everyone if j != n_agents + k], self.dt)
+                    for k, sv in enumerate(self.social)]
+            for sv, c in zip(self.social, cmds):
+                sv.body.speed_cmd = c
         # 2. controllers (smarts.py:1233-1263)
         for ag, action in zip(self.agents, actions):
             if not ag.alive:

@@ -24,6 +24,7 @@ EVENT_NAMES = ["collisions", "off_road", "off_route", "on_shoulder", "wrong_way"
 EV = {name.upper(): i for i, name in enumerate(EVENT_NAMES)}
 ACTION_SPACES = {"Lane": 0, "Continuous": 1, "ActuatorDynamic": 2, "LaneWithContinuousSpeed": 3, "Trajectory": 4}
 TRAJ_COLS = 11
+SOCIAL_MODELS = {"constant": 0, "idm": 1}
 PHASES = ["control", "scan", "ogm", "sensors", "commit", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR, SENSOR_DAGM = 1, 2, 4, 8, 16, 32
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
@@ -55,6 +56,7 @@ class SmxConfig(C.Structure):
         ("alive_min_ego", _i32), ("alive_min_total", _i32), ("alive_lists", _i32), ("alive_list_min", _i32 * 4),
         ("alive_list_mask", C.c_uint64 * 4),
         ("dagm_width", _i32), ("dagm_height", _i32), ("dagm_resolution", _f64),
+        ("social_model", _i32), ("pad_social", _i32),
     ]
 
 

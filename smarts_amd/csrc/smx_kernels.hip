@@ -228,7 +228,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
     double offset = SF(SMX_S_MCL_Y), speed, x, y, heading;
     SF(SMX_S_PREV_X) = SF(SMX_S_X);
     SF(SMX_S_PREV_Y) = SF(SMX_S_Y);
-    social_step(m, (int)(gid % c.num_vehicles), c.social_speed_factor, c.dt, lane, offset, crossed, speed);
+    // SMX_SOCIAL_IDM: k_social decided this tick's speed from the state at the start of the tick
+    const double cmd = c.social_model == SMX_SOCIAL_IDM ? SF(SMX_S_THROTTLE) : -1.0;
+    social_step(m, (int)(gid % c.num_vehicles), c.social_speed_factor, c.dt, lane, offset, crossed, speed, cmd);
     social_pose(m, lane, offset, x, y, heading);
     SF(SMX_S_X) = x;
     SF(SMX_S_Y) = y;
@@ -479,6 +481,60 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
   a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
   SMX_TSTAMP(tc7);
   SMX_TACC(20, tc0, tc7);
+}
+
+// =================================================================================
+// k_social (SMX_SOCIAL_IDM only): car following of the scripted social vehicles, one thread per
+// vehicle, before k_control moves anything: every follower reads its env-mates' poses and speeds as
+// they stand at the start of the tick and leaves its speed for the tick in SMX_S_THROTTLE (unused by a
+// kinematic vehicle).  The arithmetic is oracle/sim.py::SocialBody.idm_speed.
+// =================================================================================
+__global__ void __launch_bounds__(SMX_BLOCK) k_social(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE) || !(flags & SMX_F_SOCIAL)) return;
+  const int n_veh = c.num_vehicles;
+  const size_t env0 = (gid / n_veh) * n_veh;
+  const int slot = (int)(gid - env0);
+  const double x = SF(SMX_S_X), y = SF(SMX_S_Y), h = SF(SMX_S_HEADING), v = SF(SMX_S_U);
+  const double v0 = m.lane_speed[(int)SF(SMX_S_MCL_X)] * c.social_speed_factor;
+  const double fx = -sin(h), fy = cos(h), rx = cos(h), ry = sin(h);
+  double best = 60.0, lead_u = 0.0;
+  bool found = false;
+  for (int j = 0; j < n_veh; ++j) {
+    if (j == slot) continue;
+    const size_t og = env0 + j;
+    if (!(a.st.flags[og] & SMX_F_ALIVE)) continue;
+    const double dx = a.st.f64[(size_t)SMX_S_X * total + og] - x, dy = a.st.f64[(size_t)SMX_S_Y * total + og] - y;
+    const double lon = dx * fx + dy * fy, lat = dx * rx + dy * ry;
+    if (lon > 0.0 && lon < best && fabs(lat) < 1.6) {
+      best = lon;
+      lead_u = a.st.f64[(size_t)SMX_S_U * total + og];
+      found = true;
+    }
+  }
+  double v_new;
+  if (v0 <= 0.0) {
+    v_new = fmax(0.0, v - 4.5 * c.dt);
+  } else {
+    const double ratio = v / v0;
+    const double free_term = 1.0 - (ratio * ratio) * (ratio * ratio);
+    double inter = 0.0;
+    if (found) {
+      const double gap = fmax(best - SMX_CHASSIS_LENGTH, 0.1);
+      const double dv = v - lead_u;
+      const double sstar = 2.5 + fmax(0.0, v * 1.0 + v * dv / (2.0 * sqrt(2.6 * 4.5)));
+      const double q = sstar / gap;
+      inter = q * q;
+    }
+    const double acc = 2.6 * (free_term - inter);
+    v_new = fmin(fmax(v + acc * c.dt, 0.0), v0);
+  }
+  SF(SMX_S_THROTTLE) = v_new;
 }
 
 // =================================================================================
@@ -2202,6 +2258,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   };
   // the LDS-path form of k_control fits one wavefront per SIMD: only while the batch needs no more
   const bool lds_path = total * SMX_WP_LANES <= (size_t)1024 * 64;
+  if (is_step && c.num_social > 0 && c.social_model == SMX_SOCIAL_IDM)
+    hipLaunchKernelGGL(k_social, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
   if (is_step) {
     switch (c.action_space) {
       case SMX_ACTION_SPACE_LANE:

@@ -586,9 +586,10 @@ __device__ inline void social_pose(const MapDev& m, int lane, double offset, dou
   heading = wrap_heading(atan2(b.y - a.y, b.x - a.x) - 0.5 * SMX_PI);
 }
 
+// `cmd` >= 0: the speed decided for this tick (car following); < 0: the constant fraction of the limit
 __device__ inline void social_step(const MapDev& m, int slot, double factor, double dt, int& lane, double& offset,
-                                   int& crossed, double& speed) {
-  speed = m.lane_speed[lane] * factor;
+                                   int& crossed, double& speed, double cmd = -1.0) {
+  speed = cmd >= 0.0 ? cmd : m.lane_speed[lane] * factor;
   offset += speed * dt;
   for (int guard = 0; guard < 64; ++guard) {
     const int v1 = m.lane_shape_off[lane + 1];

@@ -63,6 +63,7 @@ class SimConfig:
     via_max: int = 0  # near-via rows per agent (the via sensor runs when BatchedSim gets vias)
     num_social: int = 0  # scripted social vehicles: the last num_social slots of every env (include/smx.h)
     social_speed_factor: float = 0.8
+    social_model: str = "constant"  # "constant" | "idm" (include/smx.h SMX_SOCIAL_*)
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
 
     def sensors_mask(self) -> int:
@@ -238,6 +239,7 @@ class BatchedSim:
                              f"(supported: {sorted(nat.ACTION_SPACES)})")
         c.action_space = nat.ACTION_SPACES[cfg.action_space]
         c.num_social, c.social_speed_factor = int(cfg.num_social), float(cfg.social_speed_factor)
+        c.social_model = nat.SOCIAL_MODELS[cfg.social_model]
         self.vias = [list(v) for v in vias] if vias is not None else None
         if self.vias is not None and cfg.via_max <= 0:
             raise ValueError("vias need SimConfig(via_max > 0)")

@@ -129,7 +129,7 @@ class BatchCore:
 
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
                  auto_reset: bool, device: str = "cuda:0", waypoint_window: Optional[Tuple[int, int]] = (4, 20),
-                 num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None):
+                 num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None, social_model: str = "constant"):
         from ..engine import BatchedSim, make_spawns
         from ..scenario_build import load_compiled_map
 
@@ -148,6 +148,7 @@ class BatchCore:
         self.cfg = sim_config_from_interface(first, num_envs, self.N, dt, auto_reset, waypoint_window, num_social,
                                              self.agent_ids)
         self.num_social = num_social
+        self.cfg.social_model = social_model
         spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)
         # mission vias (sstudio Via per agent id) -> resolved lists per vehicle slot
         self.vias = None

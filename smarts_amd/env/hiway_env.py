@@ -44,6 +44,7 @@ class HiWayEnv:
         device: str = "cuda:0",
         waypoint_window: Optional[Tuple[int, int]] = None,
         num_social: int = 0,
+        social_model: str = "constant",
         vias: Optional[Dict[str, Sequence]] = None,
     ):
         self._log = logging.getLogger(self.__class__.__name__)
@@ -69,6 +70,7 @@ class HiWayEnv:
         self._waypoint_window = waypoint_window
         # scripted social traffic (the accelerated path's stand-in for the scenario's SUMO flows)
         self._num_social = int(num_social)
+        self._social_model = social_model  # "constant" | "idm" (include/smx.h SMX_SOCIAL_*)
         # mission via points per agent id (smarts_amd.vias.Via = sstudio's Via); the reference reads them
         # from the scenario's missions, which this path does not parse
         self._vias = dict(vias) if vias else None
@@ -102,7 +104,7 @@ class HiWayEnv:
         """What must agree for envs to share one device batch (ParallelEnv)."""
         specs = self._agent_specs
         return (self._scenario, tuple(specs.keys()), tuple(repr(s.interface) for s in specs.values()), self._dt,
-                self._waypoint_window, self._num_social, repr(self._vias))
+                self._waypoint_window, self._num_social, self._social_model, repr(self._vias))
 
     def seed(self, seed: int) -> int:
         """hiway_env.py:204-214.  Takes effect at the next ``reset`` that (re)builds the spawn table."""
@@ -121,7 +123,7 @@ class HiWayEnv:
         if self._core is None:
             self._core = BatchCore(self._scenario, self._agent_specs, num_envs=1, dt=self._dt, seed=self._seed,
                                    auto_reset=False, device=self._device, waypoint_window=self._waypoint_window,
-                                   num_social=self._num_social, vias=self._vias)
+                                   num_social=self._num_social, vias=self._vias, social_model=self._social_model)
         return self._core
 
     def step(self, agent_actions) -> Tuple[Dict[str, Observation], Dict[str, float], Dict[str, bool], Dict[str, Any]]:

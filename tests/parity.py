@@ -195,7 +195,8 @@ class OracleBatch:
                 ovias = [[dict(lane_id=v.lane_id, position=v.position, hit_distance=v.hit_distance,
                                required_speed=v.required_speed) for v in lst] for lst in vias[:self.N - K]]
             self.envs.append(OracleEnv(self.road_map, spawns_ep0[rows], [ocfg] * (self.N - K), dt=cfg.dt, social=social,
-                                       social_speed_factor=cfg.social_speed_factor, vias=ovias))
+                                       social_speed_factor=cfg.social_speed_factor, vias=ovias,
+                                       social_model=cfg.social_model))
 
     def _stack(self, parts):
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}

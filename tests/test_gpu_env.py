@@ -199,6 +199,24 @@ def test_hiway_env_with_scripted_social_traffic():
     env.close()
 
 
+def test_hiway_env_social_traffic_with_car_following():
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+
+    spec = AgentSpec(interface=AgentInterface.from_type(AgentType.Laner, neighborhood_vehicles=True, max_episode_steps=40),
+                     agent_builder=lambda: Agent.from_function(lambda _: "slow_down"))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={AGENT_ID: spec}, headless=True, seed=9, num_social=12,
+                   social_model="idm")
+    obs = env.reset()
+    speeds = []
+    for _ in range(30):
+        obs, _, dones, _ = env.step({AGENT_ID: "slow_down"})
+        speeds += [v.speed for v in obs[AGENT_ID].neighborhood_vehicle_states if v.id.startswith("social-")]
+        if dones["__all__"]:
+            break
+    assert speeds and min(speeds) >= 0.0 and max(speeds) <= 16.67 + 1e-3
+    env.close()
+
+
 def test_hiway_env_tracker_agent_follows_its_waypoints():
     """AgentType.Tracker (ActionSpaceType.Trajectory): the agent sends back its first waypoint path
     with a speed profile, as the reference's examples do."""

@@ -248,6 +248,43 @@ def test_scripted_social_traffic(name, E, agents, social, T, seed, nets, compile
     sim.close()
 
 
+@pytest.mark.parametrize("name,E,agents,social,T,seed", [("loop", 3, 4, 20, 80, 54), ("4lane", 2, 4, 12, 40, 55)])
+def test_social_traffic_with_car_following(name, E, agents, social, T, seed, nets, compiled_maps):
+    """include/smx.h SMX_SOCIAL_IDM (k_social): followers read leaders (agents included) at the start of
+    the tick; device vs oracle, and the fleet keeps its distance where the constant-speed model would not."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps(name)
+    N = agents + social
+    cfg = SimConfig(num_envs=E, num_vehicles=N, num_social=social, social_model="idm", social_speed_factor=1.0,
+                    neighbors=True, nb_radius=60.0, done_collision=False)
+    spawns, where = make_spawns(cm, E, N, episodes=2, seed=seed, return_lanes=True)
+    sim = BatchedSim(cm, cfg, spawns=spawns, social_spawns=where)
+    ob = parity.OracleBatch(nets(name), cm, cfg, spawns[0], where[0])
+    d, o = _host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(seed)
+    slowed = 0
+    for t in range(T):
+        acts = _actions(rng, E, N)
+        acts[:, 0] = 1  # agent 0 of every env brakes to a stop: a standing obstacle for whoever follows it
+        d, o = _host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"{name} idm t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+        S = sim.state
+        for e, env in enumerate(ob.envs):  # the device state the sync just copied is the oracle's own
+            for k, sv in enumerate(env.social):
+                assert abs(float(S[3, e, agents + k]) - sv.body.u) < 1e-9
+        u = S[3, :, agents:]
+        limit = torch.tensor([[cm.lane_speed[int(S[12, e, agents + k])] for k in range(social)] for e in range(E)], device=u.device)
+        slowed += int((u < 0.7 * limit).sum())
+    assert slowed > 0  # somebody was held up by a leader
+    sim.close()
+
+
 @pytest.mark.parametrize("name,E,N,T,seed", [("loop", 3, 6, 40, 61), ("minicity", 2, 12, 25, 62)])
 def test_trajectory_action_space(name, E, N, T, seed, nets, compiled_maps):
     """ActionSpaceType.Trajectory (PD tracking, trajectory_tracking_controller.py:176-331): every

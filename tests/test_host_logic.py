@@ -215,3 +215,32 @@ def test_oracle_drivable_area_raster_properties(nets):
     assert np.mean(np.rot90(g, -1) == q) > 0.97
     # far from any road: nothing
     assert dagm(VehicleBody(mx + 5000.0, my, 0.0, 0.0), rmap.lane_bands(), 32, 32, 1.0).max() == 0
+
+
+def test_oracle_idm_follower_keeps_its_gap(nets):
+    """oracle/sim.py::SocialBody.idm_speed: free road -> the desired speed; a standing leader ahead in the
+    corridor -> the follower stops short of it; a vehicle beside the corridor is ignored."""
+    from oracle.dynamics import VehicleBody
+    from oracle.road_network import ORoadNetwork
+    from oracle.sim import SocialBody
+
+    rmap = ORoadNetwork(nets("loop"))
+    lane = rmap.lane_by_id(nets("loop").all_lanes()[0].getID())
+    f = SocialBody(0.0, 0.0, 0.0, 0.0, lane, 5.0, 7, 1.0)
+    f.step(0.1)  # places it on its lane
+    v0 = lane.speed_limit
+    for _ in range(400):  # free road
+        f.speed_cmd = f.idm_speed([], 0.1)
+        f.u = f.speed_cmd
+    assert f.u == pytest.approx(v0, rel=1e-3)
+    # a standing leader 40 m ahead along the heading
+    fx, fy = -np.sin(f.heading), np.cos(f.heading)
+    leader = VehicleBody(f.x + 40.0 * fx, f.y + 40.0 * fy, f.heading, 0.0)
+    beside = VehicleBody(f.x + 10.0 * fx + 3.2 * fy, f.y + 10.0 * fy - 3.2 * fx, f.heading, 0.0)
+    x, y, travelled = f.x, f.y, 0.0
+    for _ in range(600):
+        f.x, f.y = x + travelled * fx, y + travelled * fy  # straight-line stand-in for the lane
+        f.u = f.idm_speed([(0, leader), (1, beside)], 0.1)
+        travelled += f.u * 0.1
+    gap = 40.0 - travelled - 3.68
+    assert f.u < 0.05 and 0.5 < gap < 4.0  # stopped, bumper gap about the minimum gap of 2.5 m
