@@ -19,7 +19,7 @@
 //   k_commit    1 lane / vehicle        new flags (teardown), dones["__all__"], auto-reset respawn
 //
 // followed, for envs whose episode ended under auto_reset (parallel_env.py:303-309), by k_scan /
-// k_sensors / k_commit restricted to the re-created vehicles.  From 32768 vehicles on every role is
+// k_sensors / k_commit restricted to the re-created vehicles.  Above 32768 vehicles every role is
 // launched on its own (k_waypoints, k_observe, k_lidar, k_ogm; see enqueue()).  Envs are independent
 // (reference: one process per env, parallel_env.py:96-122): no inter-workgroup communication.
 #include <hip/hip_runtime.h>
@@ -2188,8 +2188,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // workgroups (k_scan halves as separate roles: 54 vs 70 us at 8 k vehicles; the OGM role inside
   // k_sensors); large batches are bound by throughput, where the same tricks cost occupancy
   // (131 k vehicles: k_scan 0.69 vs 0.52 ms split vs back-to-back, OGM inside k_sensors +6 %).
-  const bool small_batch = total < 32768;
-  const int scan_split = small_batch ? 1 : 0;
+  const bool small_batch = (total <= 32768) || (h->debug_skip & 131072);
+  const int scan_split = (small_batch || (h->debug_skip & 65536)) ? 1 : 0;
   const int scan_blocks = (scan_split ? 2 : 1) * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
   const int vpb = SMX_BLOCK / SMX_WP_LANES;
   const int wp_blocks = (int)((total + vpb - 1) / vpb);

@@ -423,7 +423,7 @@ class BatchedSim:
         ogm = (3 * 8 + 4 + o["ogm"]) if self.cfg.ogm else 0
         dagm = (3 * 8 + 4 + o["dagm"]) if self.cfg.dagm else 0  # map segments are L2-resident, not counted
         ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
-                      and self.E * self.N < 32768)  # smx_kernels.hip enqueue(): small batches only
+                      and self.E * self.N <= 32768)  # smx_kernels.hip enqueue(): small batches only
         if (self.cfg.ogm and not ogm_inline) or self.cfg.dagm:
             kb["ogm"] = (0 if ogm_inline else ogm) + dagm  # their own launches (one timing phase)
         lidar = (3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]) if self.cfg.lidar is not None else 0

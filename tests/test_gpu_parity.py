@@ -595,15 +595,15 @@ def test_full_size_properties(compiled_maps):
 
 
 def test_large_batch_launch_strategy_agrees_with_small_batch(compiled_maps):
-    """From 32768 vehicles on, k_scan runs its halves back to back and the OGM role gets its own
-    launch (smx_kernels.hip enqueue()); a 4096 x 8 batch must compute what a 32-env slice of it
+    """Above 32768 vehicles k_scan runs its halves back to back and the OGM role gets its own
+    launch (smx_kernels.hip enqueue()); a 4160 x 8 batch must compute what a 32-env slice of it
     (small-batch strategy) computes."""
     import torch
 
     from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
 
     cm = compiled_maps("4lane")
-    E, N, sub = 4096, 8, 32
+    E, N, sub = 4160, 8, 32
     spawns = make_spawns(cm, sub, N, episodes=1, seed=9)
     big = np.tile(spawns, (1, E // sub, 1))  # the slice repeated: every env group sees the same worlds
     kw = dict(num_vehicles=N, neighbors=True, nb_radius=50.0, ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
