@@ -446,7 +446,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
         }
         // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
         if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, path);
-        co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
+        if (!(a.debug_skip & 1048576)) co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
       }
       SMX_TSTAMP(tc4);
       SMX_TACC(18, tc3, tc4);
@@ -461,7 +461,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
   SMX_TSTAMP(tc5);
   SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
   SF(SMX_S_PREV_Y) = s.y;
-  vehicle_step(s, co, c.dt);
+  if (!(a.debug_skip & 2097152)) vehicle_step(s, co, c.dt);
   SMX_TSTAMP(tc6);
   SMX_TACC(19, tc5, tc6);
   SF(SMX_S_X) = s.x;
