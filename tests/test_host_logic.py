@@ -244,3 +244,18 @@ def test_oracle_idm_follower_keeps_its_gap(nets):
         travelled += f.u * 0.1
     gap = 40.0 - travelled - 3.68
     assert f.u < 0.05 and 0.5 < gap < 4.0  # stopped, bumper gap about the minimum gap of 2.5 m
+
+
+def test_bench_cpu_worker_leg_runs_without_a_gpu():
+    """bench.py's all-cores CPU leg starts children like this one; they must not need torch or a GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "1", "--cpu-seconds", "0.3"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["env_steps"] >= 4 and rec["seconds"] > 0
