@@ -1950,6 +1950,8 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
     return fail(h, SMX_ERR_INVALID, "num_social must leave at least one agent slot");
   if (c.num_social > 0 && !(c.social_speed_factor >= 0.0))
     return fail(h, SMX_ERR_INVALID, "social_speed_factor must be >= 0");
+  if (c.social_model != SMX_SOCIAL_CONSTANT && c.social_model != SMX_SOCIAL_IDM)
+    return fail(h, SMX_ERR_INVALID, "unknown social_model");
   if (c.action_space < SMX_ACTION_SPACE_LANE || c.action_space > SMX_ACTION_SPACE_TRAJECTORY)
     return fail(h, SMX_ERR_INVALID, "unknown action_space");
   if ((c.sensors & SMX_SENSOR_OGM) &&

@@ -259,3 +259,42 @@ def test_bench_cpu_worker_leg_runs_without_a_gpu():
     assert out.returncode == 0, out.stderr[-500:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["env_steps"] >= 4 and rec["seconds"] > 0
+
+
+def test_c_abi_rejects_invalid_configs_before_touching_the_device():
+    """smx_create validates the whole smx_config first (include/smx.h: 0 = OK, negative = error, message
+    from smx_last_error): no GPU is needed to be told that a config cannot run."""
+    import ctypes as C
+
+    from smarts_amd import _native as nat
+
+    lib = nat.load_library()
+
+    def create(**over):
+        c = nat.SmxConfig()
+        c.num_envs, c.num_vehicles, c.dt = 2, 4, 0.1
+        c.sensors = nat.SENSOR_WAYPOINTS | nat.SENSOR_NEIGHBORS
+        c.wp_lookahead, c.wp_paths, c.wp_len, c.nb_max, c.nb_radius = 32, 4, 20, 10, 50.0
+        for k, v in over.items():
+            setattr(c, k, v)
+        h = C.c_void_p()
+        rc = lib.smx_create(C.byref(c), 0, C.byref(h))
+        msg = lib.smx_last_error(h).decode() if h else ""
+        if h:
+            lib.smx_destroy(h)
+        return rc, msg
+
+    bad = [
+        (dict(num_vehicles=65), "num_vehicles"), (dict(num_envs=0), "num_envs"), (dict(dt=0.0), "dt"),
+        (dict(wp_len=34), "wp_len"), (dict(wp_lookahead=40), "lookahead"), (dict(wp_paths=65), "wp_paths"),
+        (dict(via_max=33), "via_max"), (dict(num_social=4), "num_social"), (dict(action_space=9), "action_space"),
+        (dict(social_model=7), "social_model"), (dict(nb_max=200), "nb_max"),
+        (dict(sensors=nat.SENSOR_OGM, ogm_width=300, ogm_height=300, ogm_resolution=0.2), "ogm"),
+        (dict(sensors=nat.SENSOR_OGM, ogm_width=64, ogm_height=64, ogm_resolution=0.0), "ogm"),
+        (dict(sensors=nat.SENSOR_DAGM, dagm_width=10, dagm_height=10, dagm_resolution=1.0), "dagm"),
+        (dict(sensors=nat.SENSOR_LIDAR, lidar_rays=0), "lidar"), (dict(alive_lists=5), "agents_alive"),
+    ]
+    for over, word in bad:
+        rc, msg = create(**over)
+        assert rc < 0 and word in msg, (over, rc, msg)
+    assert lib.smx_create(None, 0, None) < 0
