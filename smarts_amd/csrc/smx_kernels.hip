@@ -1441,6 +1441,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_commit(const KernelArgs a) { comm
 // oriented chassis rectangle; view centred on the vehicle, +row = behind, row 0 = ahead
 // (np.flipud, sensors.py:748), extent width*res x height*res (renderer.py:384-385).
 // =================================================================================
+struct OgmMate {
+  double cx, cy, vfx, vfy, vrx, vry;  // centre and axes of the footprint in the ego frame
+  int c0, r0, bw, n_px;               // pixel rectangle: first column / row, width, pixel count
+};
+
 __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
   extern __shared__ __align__(16) unsigned char tile[];
   const smx_config& c = a.cfg;
@@ -1460,31 +1465,61 @@ __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
   const double ex0 = SF(SMX_S_X), ey0 = SF(SMX_S_Y), eh = wrap_heading(SF(SMX_S_HEADING));
   const double rx = cos(eh), ry = sin(eh);    // ego right axis
   const double fx = -sin(eh), fy = cos(eh);   // ego forward axis
-  for (int j = threadIdx.x; j < n_veh; j += SMX_BLOCK) {
-    const size_t og = (size_t)env * n_veh + j;
-    if (!(a.st.flags[og] & SMX_F_ALIVE)) continue;
-    const double vx = a.st.f64[(size_t)SMX_S_X * total + og], vy = a.st.f64[(size_t)SMX_S_Y * total + og];
-    const double vh = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
-    const double dx = vx - ex0, dy = vy - ey0;
-    const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
-    const double dh = vh - eh;
-    const double vfx = -sin(dh), vfy = cos(dh), vrx = cos(dh), vry = sin(dh);
-    const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
-    const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
-    // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
-    int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
-    int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) / res) + 1;
-    c0 = max(c0, 0);
-    r0 = max(r0, 0);
-    c1 = min(c1, W - 1);
-    r1 = min(r1, H - 1);
-    for (int r = r0; r <= r1; ++r) {
-      const double py = (0.5 * H - (r + 0.5)) * res - cy;
-      for (int col = c0; col <= c1; ++col) {
-        const double px = (col + 0.5 - 0.5 * W) * res - cx;
-        if (fabs(px * vfx + py * vfy) <= hl && fabs(px * vrx + py * vry) <= hw) tile[r * W + col] = 255;
+  // Pass 1, lane j = env-mate j: its footprint in the ego frame and the pixel rectangle that can hold
+  // it.  Pass 2: the mates whose rectangle meets the view (a ballot; typically a handful of the env)
+  // are drawn one after the other with the wavefront's lanes over the rectangle's pixels — a lane per
+  // mate would make every lane wait for the mate with the most pixels while most lanes draw nothing.
+  __shared__ OgmMate mates[SMX_BLOCK];
+  const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
+  for (int base = 0; base < n_veh; base += SMX_BLOCK) {
+    const int j = base + (int)threadIdx.x;
+    bool in_view = false;
+    if (j < n_veh) {
+      const size_t og = (size_t)env * n_veh + j;
+      if (a.st.flags[og] & SMX_F_ALIVE) {
+        const double vx = a.st.f64[(size_t)SMX_S_X * total + og], vy = a.st.f64[(size_t)SMX_S_Y * total + og];
+        const double vh = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
+        const double dx = vx - ex0, dy = vy - ey0;
+        const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
+        const double dh = vh - eh;
+        const double vfx = -sin(dh), vfy = cos(dh), vrx = cos(dh), vry = sin(dh);
+        const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
+        // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
+        int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
+        int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) / res) + 1;
+        c0 = max(c0, 0);
+        r0 = max(r0, 0);
+        c1 = min(c1, W - 1);
+        r1 = min(r1, H - 1);
+        if (c0 <= c1 && r0 <= r1) {
+          in_view = true;
+          OgmMate& q = mates[threadIdx.x];
+          q.cx = cx;
+          q.cy = cy;
+          q.vfx = vfx;
+          q.vfy = vfy;
+          q.vrx = vrx;
+          q.vry = vry;
+          q.c0 = c0;
+          q.r0 = r0;
+          q.bw = c1 - c0 + 1;
+          q.n_px = (c1 - c0 + 1) * (r1 - r0 + 1);
+        }
       }
     }
+    unsigned long long todo = __ballot(in_view);
+    __syncthreads();
+    while (todo != 0ull) {  // uniform
+      const OgmMate q = mates[__ffsll((long long)todo) - 1];
+      todo &= todo - 1ull;
+      for (int p = (int)threadIdx.x; p < q.n_px; p += SMX_BLOCK) {
+        const int r = q.r0 + p / q.bw, col = q.c0 + p % q.bw;
+        const double py = (0.5 * H - (r + 0.5)) * res - q.cy;
+        const double px = (col + 0.5 - 0.5 * W) * res - q.cx;
+        if (fabs(px * q.vfx + py * q.vfy) <= hl && fabs(px * q.vrx + py * q.vry) <= hw) tile[r * W + col] = 255;
+      }
+    }
+    __syncthreads();  // before the stage is reused (envs of more than 64 vehicles do not exist, but the loop is general)
   }
   __syncthreads();
   int4* dst = reinterpret_cast<int4*>(a.out.ogm + gid * (size_t)bytes);
