@@ -813,9 +813,43 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         fwy = __shfl(gy, src, SMX_WP_LANES);
         fwh = __shfl(gh, src, SMX_WP_LANES);
         have_first_wp = n_paths_total > 0;
+      } else if (seed.n_lanes <= SMX_WP_LANES) {
+        // ---- a lane branches inside the lookahead: paths are numbered lanes by index, branches
+        // depth-first, i.e. lane p's paths follow those of the lower lanes.  The counts are known from
+        // the first pass, so an exclusive prefix over the team gives every lane the numbers of its
+        // own paths, and each lane writes its own branches again, now into the right rows (all of
+        // them: a provisional row may have been written by two lanes at once in the first pass).
+        int incl = cnt;
+        {
+          int t = __shfl_up(incl, 1, SMX_WP_LANES);
+          if (p0 >= 1) incl += t;
+          t = __shfl_up(incl, 2, SMX_WP_LANES);
+          if (p0 >= 2) incl += t;
+        }
+        n_paths_total = __shfl(incl, SMX_WP_LANES - 1, SMX_WP_LANES);
+        const int base = incl - cnt;
+        if (start >= 0 && base < P) {
+          BranchState bs;
+          bs.reset();
+          int idx = base;
+          do {
+            if (idx >= P) break;
+            WpRows rows = wp_rows(o, gid, P, W, idx);
+            const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, W,
+                                              [&](int i, const WaypointOut& w) { wp_put(m, rows, i, w); });
+            wp_zero(rows, n < W ? n : W, W);
+            o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+            ++idx;
+          } while (bs.advance());
+        }
+        const int src = started ? (__ffs(started) - 1) : 0;  // path 0 is the lowest started lane's first path
+        fwx = __shfl(gx, src, SMX_WP_LANES);
+        fwy = __shfl(gy, src, SMX_WP_LANES);
+        fwh = __shfl(gh, src, SMX_WP_LANES);
+        have_first_wp = n_paths_total > 0;
       } else {
-        // ---- number the paths the long way (lanes by index, branches depth-first): every lane
-        // walks every path to discover the branchings, lane (idx % 4) writes kept path idx
+        // ---- roads with more than four lanes: number the paths the long way (lanes by index, branches
+        // depth-first): every lane walks every path to discover the branchings, lane (idx % 4) writes kept path idx
         int idx = 0;
         for (int li = 0; li < seed.n_lanes; ++li) {
           const int st = seed_start(m, seed, li, px, py);
