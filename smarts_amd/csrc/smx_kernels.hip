@@ -817,8 +817,10 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         // ---- a lane branches inside the lookahead: paths are numbered lanes by index, branches
         // depth-first, i.e. lane p's paths follow those of the lower lanes.  The counts are known from
         // the first pass, so an exclusive prefix over the team gives every lane the numbers of its
-        // own paths, and each lane writes its own branches again, now into the right rows (all of
-        // them: a provisional row may have been written by two lanes at once in the first pass).
+        // own paths, and each lane writes its own branches again, now into the right rows.  Only a
+        // first path whose provisional row was already the right one stays as written: provisional
+        // rows are distinct (a lane's rank among the started lanes), so nobody else wrote there in the
+        // first pass, and whoever owns another lane's stale provisional row rewrites it here, later.
         int incl = cnt;
         {
           int t = __shfl_up(incl, 1, SMX_WP_LANES);
@@ -828,17 +830,24 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         }
         n_paths_total = __shfl(incl, SMX_WP_LANES - 1, SMX_WP_LANES);
         const int base = incl - cnt;
-        if (start >= 0 && base < P) {
+        const bool first_in_place = base == prov;
+        if (start >= 0 && base < P && !(cnt == 1 && first_in_place)) {
           BranchState bs;
           bs.reset();
           int idx = base;
           do {
             if (idx >= P) break;
-            WpRows rows = wp_rows(o, gid, P, W, idx);
-            const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, W,
-                                              [&](int i, const WaypointOut& w) { wp_put(m, rows, i, w); });
-            wp_zero(rows, n < W ? n : W, W);
-            o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+            if (idx == base && first_in_place) {
+              // only walked, to learn the branchings the enumeration continues from
+              equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, 0,
+                                  [&](int, const WaypointOut&) {});
+            } else {
+              WpRows rows = wp_rows(o, gid, P, W, idx);
+              const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, W,
+                                                [&](int i, const WaypointOut& w) { wp_put(m, rows, i, w); });
+              wp_zero(rows, n < W ? n : W, W);
+              o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+            }
             ++idx;
           } while (bs.advance());
         }
