@@ -48,8 +48,7 @@ __device__ unsigned long long smx_prof[24];
 __device__ __forceinline__ double py_mod(double a, double b) {
   // |a| < b is the common case on this path (angles): the remainder is then `a` itself, or
   // `a + b` for negative `a` — exactly what fmod-then-adjust yields, without the slow fmod.
-  if (a >= 0.0 && a < b) return a;
-  if (a < 0.0 && a > -b) return a + b;
+  if (a > -b && a < b) return a < 0.0 ? a + b : a;  // one branch and a select (the same values as two tests)
   double m = fmod(a, b);
   if (m != 0.0 && m < 0.0) m += b;
   return m;

@@ -596,24 +596,16 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
         ss = (sq - sj) / den;
       }
       do {
+        // np.interp returns the knot's own value when t sits on it; the expression below does too
+        // (dt_ = 0, the slopes are finite: den > 0 here), so only the lane rule needs the test
         WaypointOut o;
-        int dl;
-        if (t == jcum) {
-          o.x = jx;
-          o.y = jy;
-          o.heading = jh;
-          o.width = wj;
-          o.speed = sj;
-          dl = strict_lane;
-        } else {
-          const double dt_ = t - jcum;
-          o.x = sx * dt_ + jx;
-          o.y = sy * dt_ + jy;
-          o.heading = sh * dt_ + jh;
-          o.width = sw * dt_ + wj;
-          o.speed = ss * dt_ + sj;
-          dl = jlane;
-        }
+        const double dt_ = t - jcum;
+        o.x = sx * dt_ + jx;
+        o.y = sy * dt_ + jy;
+        o.heading = sh * dt_ + jh;
+        o.width = sw * dt_ + wj;
+        o.speed = ss * dt_ + sj;
+        const int dl = (t == jcum) ? strict_lane : jlane;
         o.heading = wrap_heading(o.heading);
         o.lane = dl;
         emit(i, o);
