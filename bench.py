@@ -8,12 +8,11 @@ A "step" is one SMARTS tick of every environment instance of the shard: controll
 dynamics, collisions, sensors/observation build, events/reward/done and auto-reset — one
 ``smx_step`` call, which enqueues the tick's kernels (k_control, k_scan, [k_ogm], k_sensors, k_commit
 and, with auto-reset, the reset pass) on one stream.
-Workload at every N: BASELINE configs[1] per GPU — scenarios/loop, 1024 batched envs x 8 Laner
-agents, waypoints (4, 20) + neighbourhood (10, 50 m) observations, dt = 0.1 s, synthetic
-spawns / action stream per SURVEY.md §8d (weak scaling: each rank owns its own 1024 envs; no
-data-path collective, only the small reward/done gather).  ``--config c3|c4|c5`` selects the
-other BASELINE configurations (at ``--envs-per-gpu`` of your choice) for profiling; the default
-line is always configs[1].
+Workload: BASELINE configs[3], the configuration the metric is quoted on — scenarios/loop, 4096 batched
+envs x 32 Laner agents, waypoints (4, 20) + neighbourhood (10, 50 m) + OGM 64 x 64 observations, dt = 0.1 s,
+synthetic spawns / action stream per SURVEY.md §8d.  ``--gpus N`` shards those 4096 envs, 4096 / N per rank
+(strong scaling, no data-path collective, only the small reward/done gather); ``--scaling weak`` gives every
+rank all 4096.  ``--config c2|c3|c5`` selects the other BASELINE configurations for profiling.
 Inputs (state, spawn table, action stream) are resident in HBM when the timed region starts.
 
 After the timed region a short second pass (not timed, not part of ``value``) re-runs the tick
@@ -204,10 +203,13 @@ def copy_peak_gbps(device, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps ticks each; the median is reported")
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="strong: the configuration's envs are sharded over the ranks (4096/N each); weak: every rank runs them all")
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="override: this many envs on every rank (weak scaling)")
     ap.add_argument("--vehicles", type=int, default=None)
     ap.add_argument("--scenario", default=None)
     ap.add_argument("--phase-steps", type=int, default=100)
@@ -239,17 +241,25 @@ def main():
         sharding.barrier()
 
     preset, scenario, cfg_kw = workload_config(args.config, args.envs_per_gpu, args.vehicles, args.scenario)
-    E, N = cfg_kw["num_envs"], cfg_kw["num_vehicles"]
-    plan = sharding.ShardPlan(total_envs=E * world, world_size=world, rank=rank)
+    N = cfg_kw["num_vehicles"]
+    # The job: the configuration's env instances, sharded one contiguous range per GPU (the
+    # reference's own data parallelism is one process per env, parallel_env.py:96-122, seeds seed + global index
+    # :190-202).  Strong scaling by default: 4096 envs in all, 4096 / N per rank.
+    weak = args.scaling == "weak" or args.envs_per_gpu is not None
+    total_envs = cfg_kw["num_envs"] * world if weak else cfg_kw["num_envs"]
+    plan = sharding.ShardPlan(total_envs=total_envs, world_size=world, rank=rank)
+    E = plan.num_envs
+    cfg_kw["num_envs"] = E
     net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", scenario))
     cm = compile_map(net)
     cfg = SimConfig(**cfg_kw)
     spawns = make_spawns(cm, E, N, episodes=4, seed=42, first_env=plan.first_env)
     sim = BatchedSim(cm, cfg, device=device, spawns=spawns)
     actions = torch.from_numpy(action_stream(E, N, 42, plan.first_env)).to(device)
-    gather = sharding.RewardDoneGather(E, N, device, world)
+    equal_shards = total_envs % world == 0  # the gather is an all_gather: equal blocks only
+    gather = sharding.RewardDoneGather(E, N, device, world if equal_shards else 1)
 
-    out = sim.reset()
+    sim.reset()
 
     def tick(i):
         gather.release(sim.next_learner_block)  # the gather of two ticks ago has read it
@@ -259,51 +269,57 @@ def main():
     for i in range(args.warmup):
         tick(i)
     gather.finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        sharding.barrier()
-    # HIP events around the launch sequence of every TIMED_EVERY-th step of the timed region (an event
-    # pair costs the stream ~6 us: on every step that is 4 % of a 0.14 ms tick)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        sampled = i % TIMED_EVERY == 0
-        if sampled:
-            sim.set_timing(True)
-        tick(args.warmup + i)
-        if sampled:
-            sim.set_timing(False)
-    gather.finish()  # every tick's gather has landed inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        sharding.barrier()
-    elapsed = time.perf_counter() - t0
+    # Timed regions: EXACTLY --steps ticks each, bracketed by barrier + synchronize on both sides, the MAX over
+    # ranks taken per region; --repeats of them back to back, the median one is the reported value (§8d).
+    # HIP events around the launch sequence of every TIMED_EVERY-th step (an event pair costs the stream ~6 us).
+    region_s = []
+    done_ticks = args.warmup
+    for rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        if world > 1:
+            sharding.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sampled = i % TIMED_EVERY == 0
+            if sampled:
+                sim.set_timing(True)
+            tick(done_ticks + i)
+            if sampled:
+                sim.set_timing(False)
+        gather.finish()  # every tick's gather has landed inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            sharding.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        region_s.append(el)
+        done_ticks += args.steps
+    elapsed = float(np.median(region_s))
     kernel_ms = sim.read_step_ms()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # per-kernel attribution pass (outside the timed region)
     phase_ms = None
     if rank == 0 and args.phase_steps > 0:
         sim.set_timing(2)
         for i in range(args.phase_steps):
-            sim.step(actions[(args.warmup + args.steps + i) % ACTION_CYCLE])
+            sim.step(actions[(done_ticks + i) % ACTION_CYCLE])
         torch.cuda.synchronize()
         phase_ms = sim.read_phase_ms().mean(axis=0)
         sim.set_timing(0)
 
     copy_peak, fill_peak = copy_peak_gbps(device, torch) if rank == 0 else (None, None)
     if rank == 0:
-        total_envs = E * world
         env_steps_per_s = total_envs * args.steps / elapsed
-        # algorithmic bytes of one launch: per agent-step, state read + state write + action +
-        # every observation / reward / done byte written (dense StdObs layout)
+        # algorithmic bytes of one launch (this rank's shard): SURVEY.md §8(d) per agent-step x E x N
         kb = sim.kernel_bytes_per_agent_step()
-        bytes_agent = sum(kb.values())
-        bytes_launch = bytes_agent * E * N
-        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-        achieved = bytes_launch / avg_kernel_s / 1e9
+        read_agent, write_agent = sum(r for r, _ in kb.values()), sum(w for _, w in kb.values())
+        bytes_agent = read_agent + write_agent
+        agents = E * N
+        avg_kernel_s = float(np.median(kernel_ms)) * 1e-3
+        achieved = bytes_agent * agents / avg_kernel_s / 1e9
         workload_key = f"{args.config}:{scenario}:{E}x{N}"
         traffic = hbm_traffic_for(workload_key)
         kernels = None
@@ -317,13 +333,18 @@ def main():
                 ms = float(ms)
                 if name == "ogm" and name not in kb:
                     continue
-                b = kb.get(name, 0) * E * N
+                r, w = kb.get(name, (0, 0))
+                b = (r + w) * agents
                 kernels["k_" + name if name != "reset" else "reset_pass"] = {
-                    "avg_ms": ms, "algorithmic_bytes": b,
+                    "avg_ms": ms, "algorithmic_bytes": b, "read_bytes": r * agents, "write_bytes": w * agents,
                     "GB/s": (b / (ms * 1e-3) / 1e9) if ms > 0 and b else None,
                 }
             obs_build_ms = float(sum(ms for n_, ms in zip(PHASES, phase_ms) if n_ in ("scan", "ogm", "sensors", "commit")))
-            dominant = max((k for k in kernels if k != "reset_pass"), key=lambda k: kernels[k]["avg_ms"])
+            # the dominant kernel of an HBM-bound path is the one that moves the most algorithmic bytes
+            dominant = max((k for k in kernels if k != "reset_pass"), key=lambda k: kernels[k]["algorithmic_bytes"])
+        sensors = ("waypoints(4x20, lookahead 32)+neighbours(10, r=50 m) obs"
+                   + (", OGM 64x64 @ 50/64 m/px" if cfg.ogm else "")
+                   + (", lidar 100 rays x 20 m" if cfg.lidar is not None else ""))
         line = {
             "metric": "aggregate env-steps/s (all agents)",
             "value": env_steps_per_s,
@@ -333,38 +354,46 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "repeats": {"n": len(region_s), "reported": "median",
+                        "env_steps_per_s": [total_envs * args.steps / t for t in region_s]},
             "config": {
-                "workload": f"scenarios/{scenario}, {E} batched envs x {N} Laner agents per GPU, "
-                            "waypoints(4x20, lookahead 32)+neighbours(10, r=50 m) obs"
-                            + (", OGM 64x64 @ 50/64 m/px" if cfg.ogm else "")
-                            + (", lidar 100 rays x 20 m" if cfg.lidar is not None else "")
-                            + f", dt=0.1, auto-reset (BASELINE.json {preset['label']})",
+                "workload": f"scenarios/{scenario}, {total_envs} batched envs x {N} Laner agents, {sensors}, dt=0.1, "
+                            f"auto-reset (BASELINE.json {preset['label']})",
+                "total_envs": total_envs,
                 "envs_per_gpu": E,
                 "vehicles_per_env": N,
                 "agent_steps_per_s": env_steps_per_s * N,
-                "sharding": f"{world} x ({E} envs), no data-path collective; per-tick reward/done all_gather",
+                "sharding": f"{world} rank(s), envs [g*{total_envs}/{world}, (g+1)*{total_envs}/{world}) on GPU g "
+                            f"({E} on rank 0); no data-path collective; per-tick reward/done all_gather (RCCL)",
                 "obs_build_ms_per_tick": obs_build_ms,
             },
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
-                "measured_copy_peak": copy_peak,
-                "measured_fill_peak": fill_peak,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "achieved_read": read_agent * agents / avg_kernel_s / 1e9,
+                "achieved_write": write_agent * agents / avg_kernel_s / 1e9,
+                "algorithmic_bytes": {"read": read_agent * agents, "write": write_agent * agents,
+                                      "total": bytes_agent * agents, "per_agent_step": bytes_agent,
+                                      "handoff_not_counted": sim.handoff_bytes_per_agent_step() * agents},
                 "traffic": traffic["bytes_per_step"] if traffic else None,
+                "traffic_read": traffic["read_bytes_per_step"] if traffic else None,
+                "traffic_write": traffic["write_bytes_per_step"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
-                "kernel": "smx_step: k_control > k_scan > [k_ogm] > k_sensors (waypoints | observe | [lidar] roles) > "
-                          "k_commit > reset pass (one launch sequence per tick; duration = HIP events around the "
-                          "sequence on its stream)",
+                "measured_copy_peak": copy_peak,
+                "measured_fill_peak": fill_peak,
+                "kernel": "smx_step of rank 0's shard: the tick's launch sequence k_control > k_scan > [k_ogm] > "
+                          "k_waypoints + k_observe [+ k_lidar] (one k_sensors launch on small batches) > k_commit > "
+                          "reset pass; duration = HIP events around the sequence on its stream, median over the "
+                          "sampled launches of the timed regions",
                 "avg_kernel_ms": avg_kernel_s * 1e3,
                 "timed_launches": int(len(kernel_ms)),
-                "bytes_per_agent_step": bytes_agent,
                 "dominant_kernel": dominant,
                 "kernels": kernels,
             },

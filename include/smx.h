@@ -243,6 +243,13 @@ enum {
 
 #define SMX_DRIVEN_PATH_LEN 500 /* DrivenPathSensor deque, sensors.py:838 */
 
+/* Element types of the caller-owned buffers (the dtype the caller declares for each pointer). */
+enum { SMX_DT_NONE = 0, SMX_DT_F64, SMX_DT_F32, SMX_DT_I32, SMX_DT_I16, SMX_DT_I8, SMX_DT_U8, SMX_DT_U64 };
+enum { /* indices into smx_state.count / .dtype: the pointers in declaration order */
+  SMX_ST_F64 = 0, SMX_ST_FLAGS, SMX_ST_STEPS, SMX_ST_ENV_TICKS, SMX_ST_ENV_DONE_COUNT, SMX_ST_ENV_EPISODE,
+  SMX_ST_DRIVEN_PATH, SMX_ST_SEED_CACHE, SMX_ST_FACTS_I32, SMX_ST_FACTS_F64, SMX_ST_ENV_RESET_PENDING,
+  SMX_ST_BUFFERS
+};
 typedef struct smx_state {
   double* f64;        /* [SMX_S_COUNT][E*N]                                    */
   int32_t* flags;     /* [E*N]  SMX_F_* bits                                   */
@@ -260,6 +267,10 @@ typedef struct smx_state {
                           -> observe kernels): nearest lane, road flags, trip-meter seed   */
   double* facts_f64;   /* [SMX_FACT_F_COUNT][E*N]: nearest-lane distance, lane heading there  */
   int32_t* env_reset_pending; /* [E] set by the observe kernel when auto_reset fires        */
+  /* what the caller allocated: element count and SMX_DT_* of each buffer above, in declaration order
+   * (SMX_ST_*); checked against the sizes smx_config implies on every entry (smx_check_buffers) */
+  uint64_t count[SMX_ST_BUFFERS];
+  uint8_t dtype[SMX_ST_BUFFERS + 5]; /* (+5: keeps the struct a multiple of 8 bytes) */
 } smx_state;
 #define SMX_SEED_COUNT 9 /* road, filter n, filter roads x2, lane count, start lanepoint x4 */
 enum {
@@ -278,6 +289,7 @@ typedef struct smx_spawns {
   int32_t episodes;
   const double* pose; /* device, [episodes][E*N][4] = x, y, heading, speed */
   const double* social; /* device, [episodes][E*N][2] = lane, arclength offset (social slots only; NULL if none) */
+  uint64_t pose_count, social_count; /* float64 elements the caller allocated for each table */
 } smx_spawns;
 
 /* ---- per-tick outputs, caller-owned device memory, dense StdObs layout
@@ -294,6 +306,15 @@ enum { /* columns of smx_outputs.ego_f32 */
   SMX_EGO_F32_COUNT = 25
 };
 
+enum { /* indices into smx_outputs.count / .dtype: the pointers in declaration order */
+  SMX_OUT_EGO_POS = 0, SMX_OUT_EGO_F32, SMX_OUT_EGO_LANE, SMX_OUT_EVENTS, SMX_OUT_REWARD, SMX_OUT_DIST, SMX_OUT_DONE,
+  SMX_OUT_ACTIVE, SMX_OUT_ENV_DONE, SMX_OUT_VIA_NEAR, SMX_OUT_VIA_NEAR_COUNT, SMX_OUT_VIA_HIT, SMX_OUT_LEARNER,
+  SMX_OUT_WP_POS, SMX_OUT_WP_HEADING, SMX_OUT_WP_LANE_WIDTH, SMX_OUT_WP_SPEED_LIMIT, SMX_OUT_WP_LANE_INDEX,
+  SMX_OUT_WP_LANE_ID, SMX_OUT_WP_COUNT, SMX_OUT_NB_POS, SMX_OUT_NB_BOX, SMX_OUT_NB_HEADING, SMX_OUT_NB_SPEED,
+  SMX_OUT_NB_LANE_INDEX, SMX_OUT_NB_LANE_ID, SMX_OUT_NB_SLOT, SMX_OUT_NB_COUNT, SMX_OUT_OGM, SMX_OUT_LIDAR_HIT,
+  SMX_OUT_LIDAR_POINT, SMX_OUT_DAGM, SMX_OUT_COLLIDEES,
+  SMX_OUT_BUFFERS
+};
 typedef struct smx_outputs {
   double* ego_pos;       /* [E*N][3]                                          */
   float* ego_f32;        /* [E*N][SMX_EGO_F32_COUNT]                          */
@@ -338,10 +359,24 @@ typedef struct smx_outputs {
   double* lidar_point;   /* ...[3]                                            */
   /* drivable-area grid map [E*N][dagm_height][dagm_width], NULL if unused     */
   uint8_t* dagm;
+  /* collisions (smarts.py:1270-1291, sensors.py:206-211): bit j = the agent's chassis touches the vehicle in
+   * slot j of its env this tick — one Collision(collidee_id) per set bit; events[SMX_EV_COLLISIONS] = any bit */
+  uint64_t* collidees;   /* [E*N]                                             */
+  /* what the caller allocated: element count and SMX_DT_* of each buffer above, in declaration order
+   * (SMX_OUT_*); 0 / SMX_DT_NONE for a NULL pointer */
+  uint64_t count[SMX_OUT_BUFFERS];
+  uint8_t dtype[SMX_OUT_BUFFERS + 7]; /* (+7: keeps the struct a multiple of 8 bytes) */
 } smx_outputs;
 
 /* ---- entry points ---- */
+/* On failure no handle is left behind (*out = NULL); smx_last_error(NULL) then gives the reason. */
 int smx_create(const smx_config* cfg, int device, smx_handle* out);
+/* The entry check of smx_reset / smx_step*, callable on its own and without a device: every buffer the
+ * configuration needs is non-NULL, declared with the expected SMX_DT_* and at least as many elements as
+ * the configuration implies (a short buffer would be an out-of-bounds device write).  `has_vias`: vias
+ * were given (smx_set_vias).  Returns SMX_OK or SMX_ERR_INVALID with the reason in err[err_len]. */
+int smx_check_buffers(const smx_config* cfg, int has_vias, const smx_state* st, const smx_spawns* sp,
+                      const smx_outputs* out, char* err, uint64_t err_len);
 int smx_load_map(smx_handle h, const smx_map_tables* map);
 /* Via points of the agents' missions (plan.py:180-188; ViaSensor sensors.py:1090-1149).  One list per
  * agent slot, shared by every env: vias[slot_off[s] .. slot_off[s+1]) belong to slot s (at most 32
@@ -402,6 +437,12 @@ uint64_t smx_struct_size(int which);
 /* Lateral gains of the lane-following controller for target_speed > 0
  * (lane_following_controller.py:420-430); defaults are the sedan's clip bounds (0.04, 3.4). */
 int smx_set_controller_gains(smx_handle h, double heading_gain, double lateral_gain);
+/* How a tick is cut into launches.  The same role functions run either way and the results are the same;
+ * the forms differ in what bounds them.  SMALL: few launches whose workgroups take different roles (a batch
+ * that cannot fill the chip is bound by one wavefront's latency); LARGE: one launch per role, waypoint rows
+ * emitted in memory order from LDS knot tables (bound by throughput).  AUTO picks by vehicle count. */
+enum { SMX_LAUNCH_AUTO = 0, SMX_LAUNCH_SMALL = 1, SMX_LAUNCH_LARGE = 2 };
+int smx_set_launch_strategy(smx_handle h, int strategy);
 const char* smx_version(void);
 void smx_destroy(smx_handle h);
 

@@ -75,10 +75,15 @@ class SmxMapTables(C.Structure):
     ]
 
 
+# SMX_DT_* (include/smx.h): the dtype the caller declares for each buffer
+DT_NONE, DT_F64, DT_F32, DT_I32, DT_I16, DT_I8, DT_U8, DT_U64 = range(8)
+STATE_BUFFERS = ["f64", "flags", "steps", "env_ticks", "env_done_count", "env_episode", "driven_path", "seed_cache",
+                 "facts_i32", "facts_f64", "env_reset_pending"]
+
+
 class SmxState(C.Structure):
-    _fields_ = [("f64", _p), ("flags", _p), ("steps", _p), ("env_ticks", _p), ("env_done_count", _p),
-                ("env_episode", _p), ("driven_path", _p), ("seed_cache", _p), ("facts_i32", _p), ("facts_f64", _p),
-                ("env_reset_pending", _p)]
+    _fields_ = [(name, _p) for name in STATE_BUFFERS] + [
+        ("count", C.c_uint64 * len(STATE_BUFFERS)), ("dtype", C.c_uint8 * (len(STATE_BUFFERS) + 5))]
 
 
 class SmxVia(C.Structure):
@@ -86,14 +91,14 @@ class SmxVia(C.Structure):
 
 
 class SmxSpawns(C.Structure):
-    _fields_ = [("episodes", _i32), ("pose", _p), ("social", _p)]
+    _fields_ = [("episodes", _i32), ("pose", _p), ("social", _p), ("pose_count", C.c_uint64), ("social_count", C.c_uint64)]
 
 
 OUTPUT_FIELDS = [
     "ego_pos", "ego_f32", "ego_lane", "events", "reward", "dist", "done", "active", "env_done", "learner",
     "wp_pos", "wp_heading", "wp_lane_width", "wp_speed_limit", "wp_lane_index", "wp_lane_id", "wp_count",
     "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
-    "ogm", "lidar_hit", "lidar_point", "dagm",
+    "ogm", "lidar_hit", "lidar_point", "dagm", "collidees",
 ]
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("learner"), "via_hit")
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_hit"), "via_near_count")
@@ -101,13 +106,32 @@ OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_near_count"), "via_near")
 
 
 class SmxOutputs(C.Structure):
-    _fields_ = [(name, _p) for name in OUTPUT_FIELDS]
+    _fields_ = [(name, _p) for name in OUTPUT_FIELDS] + [
+        ("count", C.c_uint64 * len(OUTPUT_FIELDS)), ("dtype", C.c_uint8 * (len(OUTPUT_FIELDS) + 7))]
+
+
+def torch_dtype_code(t) -> int:
+    """SMX_DT_* of a torch tensor (the dtype enum checked on entry, include/smx.h)."""
+    import torch
+
+    return {torch.float64: DT_F64, torch.float32: DT_F32, torch.int32: DT_I32, torch.int16: DT_I16, torch.int8: DT_I8,
+            torch.uint8: DT_U8, torch.int64: DT_U64, torch.uint64: DT_U64}[t.dtype]
+
+
+def bind_buffer(struct, names, name, tensor):
+    """Point field `name` of an SmxState / SmxOutputs at `tensor` (None = NULL) and declare its extent."""
+    k = names.index(name)
+    setattr(struct, name, tensor.data_ptr() if tensor is not None else None)
+    struct.count[k] = int(tensor.numel()) if tensor is not None else 0
+    struct.dtype[k] = torch_dtype_code(tensor) if tensor is not None else DT_NONE
 
 
 EXPORTS = [
     "smx_create", "smx_load_map", "smx_set_vias", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
+    "smx_check_buffers", "smx_set_launch_strategy",
 ]
+LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2}
 
 _lib: Optional[C.CDLL] = None
 
@@ -172,6 +196,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_version.restype = C.c_char_p
     lib.smx_destroy.argtypes = [h]
     lib.smx_destroy.restype = None
+    lib.smx_check_buffers.argtypes = [C.POINTER(SmxConfig), C.c_int, C.POINTER(SmxState), C.POINTER(SmxSpawns),
+                                      C.POINTER(SmxOutputs), C.c_char_p, C.c_uint64]
+    lib.smx_check_buffers.restype = C.c_int
+    lib.smx_set_launch_strategy.argtypes = [h, C.c_int]
+    lib.smx_set_launch_strategy.restype = C.c_int
     lib.smx_struct_size.argtypes = [C.c_int]
     lib.smx_struct_size.restype = C.c_uint64
     for which, mirror in enumerate((SmxConfig, SmxMapTables, SmxState, SmxSpawns, SmxOutputs)):

@@ -32,7 +32,7 @@ __device__ double smx_dbg_f[64];
 
 // Developer build (-DSMX_DEBUG_TIMING): per-phase wave-clock accumulation.
 #ifdef SMX_DEBUG_TIMING
-__device__ unsigned long long smx_prof[24];
+__device__ unsigned long long smx_prof[32];
 #define SMX_TSTAMP(var) unsigned long long var = wall_clock64()
 #define SMX_TACC(slot, t0, t1) \
   do { if ((threadIdx.x & 63) == 0) atomicAdd(&smx_prof[slot], (t1) - (t0)); } while (0)

@@ -62,9 +62,19 @@ struct KernelArgs {
   int debug_skip;
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
   double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
+  KnotLists knots;          // library-owned hand-off: k_wp_walk -> k_waypoints_tables
 };
 
 #define SF(field) a.st.f64[(size_t)(field) * total + gid]
+
+// Developer timing switches ("switch a piece off and see what the tick costs without it"): they exist
+// only in the -DSMX_DEBUG_TIMING variant of the library (smarts_amd/build.py --prof); in the shipped
+// library the test is the constant false and nothing, environment included, can drop work from a tick.
+#ifdef SMX_DEBUG_TIMING
+#define SMX_SKIP(args, bit) (((args).debug_skip & (bit)) != 0)
+#else
+#define SMX_SKIP(args, bit) false
+#endif
 
 // ---------------------------------------------------------------------------------
 // oriented-box proximity (substitution for pybullet getClosestPoints)
@@ -299,7 +309,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
     }
     cs.steer = co.steering;  // last_steering_angle / the persisting steer target
   }
-  if (has_action && lane_following && !(a.debug_skip & 1)) {  // uniform within a team
+  if (has_action && lane_following && !SMX_SKIP(a, 1)) {  // uniform within a team
     double target_speed;
     int lane_change;
     double hg, lg;
@@ -446,7 +456,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
         }
         // beyond the team's first seed lanes (roads with more than 4 lanes): serial search
         if (!owners) ctrl_path_serial(m, seed, px, py, want, knots, SMX_BLOCK, path);
-        if (!(a.debug_skip & 1048576)) co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
+        if (!SMX_SKIP(a, 1048576)) co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
       }
       SMX_TSTAMP(tc4);
       SMX_TACC(18, tc3, tc4);
@@ -461,7 +471,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
   SMX_TSTAMP(tc5);
   SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
   SF(SMX_S_PREV_Y) = s.y;
-  if (!(a.debug_skip & 2097152)) vehicle_step(s, co, c.dt);
+  if (!SMX_SKIP(a, 2097152)) vehicle_step(s, co, c.dt);
   SMX_TSTAMP(tc6);
   SMX_TACC(19, tc5, tc6);
   SF(SMX_S_X) = s.x;
@@ -552,8 +562,8 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TSTAMP(ts0);
   const VehState s = load_vehicle(a, gid, total);
   int32_t* fi = a.st.facts_i32;
-  if ((a.debug_skip & 512) && role == 1) return;
-  if ((a.debug_skip & 1024) && role == 0) return;
+  if (SMX_SKIP(a, 512) && role == 1) return;
+  if (SMX_SKIP(a, 1024) && role == 0) return;
   if (role == 0) {
     // ---- road facts
     const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
@@ -574,8 +584,8 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
     // nearest lane closest to the vehicle; junction lanes are exempt (:548-551)
     double lane_heading = 0.0;
-    if (a.debug_skip & 2048) return;
-    const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !(a.debug_skip & 64);  // uniform in the team
+    if (SMX_SKIP(a, 2048)) return;
+    const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !SMX_SKIP(a, 64);  // uniform in the team
     if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
     SMX_TSTAMP(ts2);
     SMX_TACC(11, ts1, ts2);
@@ -597,9 +607,9 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   SMX_TACC(12, ts3, ts4);
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   // what the controller (and the waypoints sensor) ask: paths at this pose with the agent's route
-  if (a.debug_skip & 4096) return;
+  if (SMX_SKIP(a, 4096)) return;
   Top10Scores sc;
-  if (a.debug_skip & 256) {
+  if (SMX_SKIP(a, 256)) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) sc.rel[k] = 0.0;
   } else {
@@ -736,7 +746,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
   if (gid >= total) return;  // whole teams leave together
-  if (a.debug_skip & 16384) return;
+  if (SMX_SKIP(a, 16384)) return;
   SMX_TSTAMP(tw0);
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
@@ -768,7 +778,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
     int n_paths_total = 0;
     SMX_TSTAMP(tw1);
     SMX_TACC(0, tw0, tw1);
-    if (seed.road >= 0 && !(a.debug_skip & 16)) {
+    if (seed.road >= 0 && !SMX_SKIP(a, 16)) {
       // ---- the guess: seed lane p holds exactly one path
       const int start = (p0 < seed.n_lanes) ? seed_start(m, seed, p0, px, py) : -1;
       int started = start >= 0 ? (1 << p0) : 0;
@@ -783,7 +793,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
         do {
           if (cnt == 0 && prov < P) {
             WpRows rows = wp_rows(o, gid, P, W, prov);
-            if (a.debug_skip & 32768) rows.pos = nullptr;
+            if (SMX_SKIP(a, 32768)) rows.pos = nullptr;
             const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, KSTRIDE, W,
                                               [&](int i, const WaypointOut& w) {
                                                 if (i == 0) {
@@ -967,6 +977,403 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
 }
 
 // =================================================================================
+// waypoints role, staged form (large batches): the same rows as waypoints_for, written as whole
+// contiguous pieces.  The chain walks are k_wp_walk's (one lane per path, nothing else, many wavefronts per
+// SIMD); this kernel re-reads the knots with independent loads.  A workgroup = one wavefront = 16 vehicles x
+// 4 team lanes:
+//   1. number — the team exchanges what k_wp_walk found; when no lane branches inside the lookahead (almost
+//               always) path numbers are the lanes' ranks among the started lanes, and every output row of
+//               the vehicle is bound to a team lane, or to "zeros";
+//   2. stage  — every lane interpolates its own path (interpolate_knots: the serial emitter's arithmetic,
+//               one path per lane, all lanes busy) into an LDS stage [waypoint][lane] of 16-byte cells;
+//   3. copy   — the wavefront's lanes sweep the 16 x P x W waypoint slots of its vehicles in memory order
+//               (rows of consecutive vehicles are adjacent in every output array): lane l takes element
+//               e = 64 k + l and copies its cell, or zeros.  A store instruction writes 64 consecutive
+//               elements.
+// Steps 2-3 run twice over the same stage: positions (x, y: 16 bytes), then heading / lane width / speed limit
+// / lane id / lane index (packed into 16 bytes); the interpolation is cheap next to a second stage's LDS.
+// Teams that need more — a branching inside the lookahead, a road with more than four lanes, a knot list
+// cut at SMX_WPK_CAP — write their rows afterwards with the serial emitter, exactly as waypoints_for does;
+// their rows are skipped in step 3.
+// =================================================================================
+#define SMX_WPT_MAX_PATHS 8  // dense rows per vehicle (wp_paths) the table form handles
+#define SMX_WPT_VEHICLES (SMX_BLOCK / SMX_WP_LANES)
+enum { SMX_ROW_SKIP = -2, SMX_ROW_ZERO = -1 };
+
+struct WpRowBook {  // which table column feeds which output row of the workgroup's vehicles
+  short src[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];          // column, SMX_ROW_ZERO or SMX_ROW_SKIP
+  unsigned char count[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];  // wp_count of the row
+  unsigned char paths[SMX_WPT_VEHICLES];                     // total number of paths of the vehicle
+  unsigned char tabled[SMX_WPT_VEHICLES];                    // the vehicle's counts come from this book
+};
+
+// Every path of the vehicle the long way (lanes by index, branches depth-first): every team lane walks
+// every path to discover the branchings, lane (idx % 4) writes kept path idx; rows of the paths that do
+// not exist are zeroed.  Returns the number of paths; lane 0 of the team learns the first waypoint.
+template <int KSTRIDE>
+__device__ inline int waypoints_long_way(const KernelArgs& a, const MapDev& m, const PathSeeds& seed, size_t gid, int p0,
+                                         double px, double py, int* knots, bool& have_first_wp, double& fwx, double& fwy,
+                                         double& fwh) {
+  const smx_outputs& o = a.out;
+  const int P = a.cfg.wp_paths, W = a.cfg.wp_len, lookahead = a.cfg.wp_lookahead;
+  int idx = 0;
+  for (int li = 0; li < seed.n_lanes; ++li) {
+    const int st = seed_start(m, seed, li, px, py);
+    if (st < 0) continue;
+    BranchState bs;
+    bs.reset();
+    do {
+      const bool kept = idx < P && (idx % SMX_WP_LANES) == p0;
+      const bool first_path = (idx == 0 && p0 == 0);
+      if (kept || first_path) {
+        WpRows rows = wp_rows(o, gid, P, W, kept ? idx : 0);
+        const int n = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, KSTRIDE, kept ? W : 1,
+                                          [&](int i, const WaypointOut& w) {
+                                            if (first_path && i == 0) {
+                                              have_first_wp = true;
+                                              fwx = w.x;
+                                              fwy = w.y;
+                                              fwh = w.heading;
+                                            }
+                                            if (kept) wp_put(m, rows, i, w);
+                                          });
+        if (kept) {
+          wp_zero(rows, n < W ? n : W, W);
+          o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+        }
+      } else if (p0 == 0 || idx < P) {
+        equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, KSTRIDE, 0, [&](int, const WaypointOut&) {});
+      }
+      ++idx;
+    } while (bs.advance() && (p0 == 0 || idx < P));
+  }
+  const int n_paths_total = __shfl(idx, 0, SMX_WP_LANES);  // lane 0 counts them all
+  for (int slot = n_paths_total + ((p0 - n_paths_total) & (SMX_WP_LANES - 1)); slot < P; slot += SMX_WP_LANES) {
+    wp_zero(wp_rows(o, gid, P, W, slot), 0, W);
+    o.wp_count[gid * (P + 1) + 1 + slot] = 0;
+  }
+  if (p0 == 0) o.wp_count[gid * (P + 1)] = (uint8_t)(n_paths_total > 255 ? 255 : n_paths_total);
+  return n_paths_total;
+}
+
+// Trip meter (sensors.py:880-947) and reward = its increment (agent_manager.py:233-234): lane 0 of the team.
+template <int KSTRIDE>
+__device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const MapDev& m, size_t gid, size_t total, int flags,
+                                                  double px, double py, int* knots, bool have_first_wp, double fwx,
+                                                  double fwy, double fwh) {
+  const smx_outputs& o = a.out;
+  double dist = SF(SMX_S_DIST);
+  int32_t* trip_has_wp_p = a.st.facts_i32 + (size_t)SMX_FI_TRIP_HAS_WP * total + gid;
+  bool trip_has_wp = *trip_has_wp_p != 0;
+  if (flags & SMX_F_FIRST) {
+    // TripMeterSensor.__init__: first waypoint of the lowest lane, lookahead-1 path, no route
+    trip_has_wp = false;
+    const int ts = a.st.facts_i32[(size_t)SMX_FI_TRIP_START * total + gid];
+    if (ts >= 0) {
+      BranchState bs;
+      bs.reset();
+      RouteFilter nof;
+      nof.n = 0;
+      equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
+        SF(SMX_S_TRIP_X) = w.x;
+        SF(SMX_S_TRIP_Y) = w.y;
+        SF(SMX_S_TRIP_H) = w.heading;
+        trip_has_wp = true;
+      });
+    }
+    dist = 0.0;
+  }
+  const double last_dist = dist;
+  if (have_first_wp) {
+    if (!trip_has_wp) {
+      SF(SMX_S_TRIP_X) = fwx;
+      SF(SMX_S_TRIP_Y) = fwy;
+      SF(SMX_S_TRIP_H) = fwh;
+      trip_has_wp = true;
+    } else {
+      double tx = SF(SMX_S_TRIP_X), ty = SF(SMX_S_TRIP_Y), th = SF(SMX_S_TRIP_H);
+      double dx = fwx - tx, dy = fwy - ty;
+      double nrm = sqrt(dx * dx + dy * dy);
+      if (nrm > 0.5) {
+        double hvx, hvy;
+        radians_to_vec(th, hvx, hvy);
+        double dot = hvx * dx + hvy * dy;
+        double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
+        dist += sgn * nrm;
+        SF(SMX_S_TRIP_X) = fwx;
+        SF(SMX_S_TRIP_Y) = fwy;
+        SF(SMX_S_TRIP_H) = fwh;
+      }
+    }
+  }
+  SF(SMX_S_DIST) = dist;
+  o.dist[gid] = dist;
+  if (!a.keep_reward_done) {
+    o.reward[gid] = dist - last_dist;
+    if (o.learner) o.learner[gid] = (float)(dist - last_dist);
+  }
+  *trip_has_wp_p = trip_has_wp ? 1 : 0;  // the flags word itself is not written here (the observe role owns it)
+}
+
+// k_wp_walk: the chain walks of the waypoints sensor, one lane per (vehicle, seed lane) and nothing else —
+// no LDS, few registers, so that many wavefronts per SIMD hide the dependent loads.  Leaves the knot list of
+// the seed lane's first path and the number of paths that start there (KnotLists).
+__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t paths = total * SMX_WP_LANES;
+  const size_t path = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (path >= paths) return;
+  const size_t gid = path / SMX_WP_LANES;
+  const int p0 = (int)(path % SMX_WP_LANES);
+  const int flags = a.st.flags[gid];
+  int n = 0, nk = 0, cnt = 0;
+  double D = 0.0;
+  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST))) {
+    const PathSeeds seed = load_seeds(a, gid, total);
+    if (seed.road >= 0 && seed.n_lanes <= SMX_WP_LANES && p0 < seed.n_lanes) {
+      const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
+      const int start = seed_start(m, seed, p0, px, py);
+      if (start >= 0) {
+        a.knots.idx[path] = start;
+        BranchState bs;
+        bs.reset();
+        const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [&](int k, int idx) {
+          if (k <= SMX_WPK_CAP) a.knots.idx[(size_t)k * paths + path] = idx;
+        });
+        n = w.n;
+        nk = w.nk;
+        D = w.D;
+        cnt = 1;
+        while (bs.advance()) {
+          walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [](int, int) {});
+          if (cnt < 255) ++cnt;
+        }
+      }
+    }
+  }
+  a.knots.n[path] = (int16_t)n;
+  a.knots.nk[path] = (int16_t)nk;
+  a.knots.cnt[path] = (uint8_t)cnt;
+  a.knots.D[path] = D;
+}
+
+struct __align__(16) WpStageCell {  // second pass: everything of a waypoint but its position
+  float heading, width, speed;
+  short lane;
+  signed char lane_index;
+  signed char pad;
+};
+
+__device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const int block) {
+  extern __shared__ __align__(16) unsigned char stage_raw[];  // [wp_len][SMX_BLOCK] cells of 16 bytes
+  __shared__ WpRowBook book;
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const smx_outputs& o = a.out;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int P = c.wp_paths, W = c.wp_len, lookahead = c.wp_lookahead;
+  const int p0 = threadIdx.x % SMX_WP_LANES, v = threadIdx.x / SMX_WP_LANES;
+  const size_t gid0 = (size_t)block * SMX_WPT_VEHICLES;
+  const size_t gid = gid0 + v;
+  const size_t path = gid * SMX_WP_LANES + p0, paths = total * SMX_WP_LANES;
+  const int col = threadIdx.x;
+  SMX_TSTAMP(tw0);
+  int flags = gid < total ? a.st.flags[gid] : 0;
+  const bool live = gid < total && (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST));
+  double px = 0.0, py = 0.0;
+  PathSeeds seed;
+  seed.road = -1;
+  seed.n_lanes = 0;
+  seed.f.n = 0;
+  int n_first = 0, nk = 0, cnt = 0;
+  double D = 0.0;
+  if (live) {
+    px = SF(SMX_S_X);
+    py = SF(SMX_S_Y);
+    seed = load_seeds(a, gid, total);
+    n_first = a.knots.n[path];  // what k_wp_walk found on seed lane p0 (0: no path starts there)
+    nk = a.knots.nk[path];
+    cnt = a.knots.cnt[path];
+    D = a.knots.D[path];
+  }
+  SMX_TSTAMP(tw1);
+  SMX_TACC(0, tw0, tw1);
+  // ---- 1. number the paths
+  const bool seeded = live && seed.road >= 0;
+  const bool long_way = seeded && seed.n_lanes > SMX_WP_LANES;  // uniform in the team
+  int started = n_first > 0 ? (1 << p0) : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) started |= __shfl_xor(started, msk, SMX_WP_LANES);
+  const int prov = __popc(started & ((1 << p0) - 1));  // this lane's path number if nobody branches
+  int branching = (cnt > 1) ? 1 : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) branching |= __shfl_xor(branching, msk, SMX_WP_LANES);
+  // the team's rows come from the stage unless it has to number its paths the long way
+  const bool serial_team = seeded && (long_way || branching != 0);  // uniform in the team
+  const int n_paths_staged = __popc(started);
+  const bool staged = n_first > 0 && !serial_team;            // this lane interpolates a path
+  const bool listed = nk <= SMX_WPK_CAP;                      // ... from a complete knot list
+  const bool my_row = staged && prov < P;                     // ... that one of the kept rows holds
+  if (p0 == 0) {
+    book.tabled[v] = (live && !serial_team) ? 1 : 0;
+    book.paths[v] = (unsigned char)(seeded ? n_paths_staged : 0);
+  }
+  for (int slot = p0; slot < P; slot += SMX_WP_LANES) {
+    // rows without a path read zeros; a dead / absent vehicle's rows are not this kernel's to write
+    book.src[v * P + slot] = (short)((live && !serial_team) ? SMX_ROW_ZERO : SMX_ROW_SKIP);
+    book.count[v * P + slot] = 0;
+  }
+  __syncthreads();  // (one wavefront: orders the LDS writes of the team's other lanes)
+  if (my_row) {
+    book.src[v * P + prov] = (short)(listed ? col : SMX_ROW_SKIP);
+    book.count[v * P + prov] = (unsigned char)min(n_first, W);
+  }
+  // ---- 2 + 3, positions
+  const smx_lp_rec r0 = (staged && listed) ? load_lp(m, a.knots.idx[path], 46) : smx_lp_rec{};
+  auto fetch = [&](int k) { return a.knots.idx[(size_t)(k + 1) * paths + path]; };
+  const int elems = SMX_WPT_VEHICLES * P * W;
+  const size_t q0 = gid0 * (size_t)P * W;
+  double gx = 0.0, gy = 0.0, gh = 0.0;  // first waypoint of this lane's path
+  {
+    double2* stage = reinterpret_cast<double2*>(stage_raw);
+    if (staged && listed)
+      interpolate_knots(m, r0, nk, n_first, D, px, py, my_row ? W : 1, fetch, [&](int i, const WaypointOut& w) {
+        if (i == 0) {
+          gx = w.x;
+          gy = w.y;
+        }
+        stage[i * SMX_BLOCK + col] = make_double2(w.x, w.y);
+      });
+    __syncthreads();
+    SMX_TSTAMP(tw2);
+    SMX_TACC(1, tw1, tw2);
+    int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per round
+    const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
+    for (int e = threadIdx.x; e < elems; e += SMX_BLOCK) {
+      const int src = book.src[row];
+      if (src != SMX_ROW_SKIP) {
+        double2 xy = make_double2(0.0, 0.0);
+        if (src >= 0 && i < (int)book.count[row]) xy = stage[i * SMX_BLOCK + src];
+        double* dst = o.wp_pos + (q0 + e) * 3;
+        dst[0] = xy.x;
+        dst[1] = xy.y;
+        dst[2] = 0.0;
+      }
+      row += drow;
+      i += di;
+      if (i >= W) {
+        i -= W;
+        ++row;
+      }
+    }
+    __syncthreads();  // the stage is reused
+    SMX_TSTAMP(tw2b);
+    SMX_TACC(24, tw2, tw2b);
+  }
+  SMX_TSTAMP(tw3);
+  // ---- 2 + 3, the other fields
+  {
+    WpStageCell* stage = reinterpret_cast<WpStageCell*>(stage_raw);
+    if (staged && listed) {
+      int cached_lane = -1, cached_index = 0;  // consecutive waypoints mostly share their lane
+      interpolate_knots(m, r0, nk, n_first, D, px, py, my_row ? W : 1, fetch, [&](int i, const WaypointOut& w) {
+        if (i == 0) gh = w.heading;
+        if (w.lane != cached_lane) {
+          cached_lane = w.lane;
+          cached_index = m.lane_index[w.lane];
+        }
+        WpStageCell cell;
+        cell.heading = (float)w.heading;
+        cell.width = (float)w.width;
+        cell.speed = (float)w.speed;
+        cell.lane = (short)w.lane;
+        cell.lane_index = (signed char)cached_index;
+        cell.pad = 0;
+        stage[i * SMX_BLOCK + col] = cell;
+      });
+    }
+    __syncthreads();
+    SMX_TSTAMP(tw3b);
+    SMX_TACC(25, tw3, tw3b);
+    int row = threadIdx.x / W, i = threadIdx.x - row * W;
+    const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
+    for (int e = threadIdx.x; e < elems; e += SMX_BLOCK) {
+      const int src = book.src[row];
+      if (src != SMX_ROW_SKIP) {
+        WpStageCell cell;
+        cell.heading = 0.0f;
+        cell.width = 0.0f;
+        cell.speed = 0.0f;
+        cell.lane = -1;
+        cell.lane_index = 0;
+        if (src >= 0 && i < (int)book.count[row]) cell = stage[i * SMX_BLOCK + src];
+        const size_t q = q0 + e;
+        o.wp_heading[q] = cell.heading;
+        o.wp_lane_width[q] = cell.width;
+        o.wp_speed_limit[q] = cell.speed;
+        o.wp_lane_id[q] = cell.lane;
+        o.wp_lane_index[q] = cell.lane_index;
+      }
+      row += drow;
+      i += di;
+      if (i >= W) {
+        i -= W;
+        ++row;
+      }
+    }
+    // wp_count: [vehicle][0] = number of paths, [1 + slot] = waypoints kept of the path in that row
+    const int cells = SMX_WPT_VEHICLES * (P + 1);
+    for (int e = threadIdx.x; e < cells; e += SMX_BLOCK) {
+      const int vv = e / (P + 1), qq = e - vv * (P + 1);
+      if (!book.tabled[vv]) continue;
+      o.wp_count[gid0 * (size_t)(P + 1) + e] = qq == 0 ? book.paths[vv] : book.count[vv * P + qq - 1];
+    }
+    SMX_TSTAMP(tw3c);
+    SMX_TACC(26, tw3b, tw3c);
+  }
+  __syncthreads();  // the stage is done with: its memory becomes the serial emitter's knot scratch
+  SMX_TSTAMP(tw4);
+  SMX_TACC(2, tw3, tw4);
+  int* knots = reinterpret_cast<int*>(stage_raw) + threadIdx.x;
+  bool have_first_wp = false;
+  double fwx = 0.0, fwy = 0.0, fwh = 0.0;
+  if (live) {
+    if (serial_team) {
+      waypoints_long_way<SMX_BLOCK>(a, m, seed, gid, p0, px, py, knots, have_first_wp, fwx, fwy, fwh);
+    } else {
+      if (staged && !listed) {
+        // more knots than the list holds: this path leaves through the serial emitter (its own walk)
+        BranchState bs;
+        bs.reset();
+        WpRows rows = wp_rows(o, gid, P, W, my_row ? prov : 0);
+        const int n = equally_spaced_path(m, seed.f, bs, a.knots.idx[path], lookahead, px, py, knots, SMX_BLOCK, my_row ? W : 1,
+                                          [&](int i, const WaypointOut& w) {
+                                            if (i == 0) {
+                                              gx = w.x;
+                                              gy = w.y;
+                                              gh = w.heading;
+                                            }
+                                            if (my_row) wp_put(m, rows, i, w);
+                                          });
+        if (my_row) wp_zero(rows, n < W ? n : W, W);
+      }
+      const int src = started ? (__ffs(started) - 1) : 0;  // path 0 is the lowest started lane's
+      fwx = __shfl(gx, src, SMX_WP_LANES);
+      fwy = __shfl(gy, src, SMX_WP_LANES);
+      fwh = __shfl(gh, src, SMX_WP_LANES);
+      have_first_wp = n_paths_staged > 0;
+    }
+  }
+  SMX_TSTAMP(tw5);
+  SMX_TACC(5, tw4, tw5);
+  if (live && p0 == 0) trip_meter_update<SMX_BLOCK>(a, m, gid, total, flags, px, py, knots, have_first_wp, fwx, fwy, fwh);
+  SMX_TSTAMP(tw6);
+  SMX_TACC(3, tw0, tw6);
+}
+
+// =================================================================================
 // observe role: the rest of Sensors.observe (sensors.py:238-396) and the events / done logic
 // (sensors.py:443-594), one thread per vehicle, whole envs per workgroup (env-mates' poses in LDS)
 // =================================================================================
@@ -1010,6 +1417,7 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
   o.ego_lane[gid * 2] = -1;
   o.ego_lane[gid * 2 + 1] = -1;
   for (int k = 0; k < SMX_EV_COUNT; ++k) o.events[gid * SMX_EV_COUNT + k] = 0;
+  if (o.collidees) o.collidees[gid] = 0ull;
   o.reward[gid] = 0.0;
   o.dist[gid] = 0.0;
   if (c.sensors & SMX_SENSOR_WAYPOINTS) {
@@ -1077,7 +1485,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   const size_t gid = valid ? ((size_t)env * n_veh + slot) : 0;
   const SharedPose* env_pose = pose + env_local * n_veh;
 
-  if (a.debug_skip & 8192) return;
+  if (SMX_SKIP(a, 8192)) return;
   SMX_TSTAMP(to0);
   VehState s = {0, 0, 0, 0, 0, 0, 0};
   int flags = 0;
@@ -1130,7 +1538,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
 
     // ---- collisions (smarts.py:1270-1291): a new vehicle has not been through a physics step
     bool collided = false;
-    if (!first && !(a.debug_skip & 4)) {
+    unsigned long long collidee_mask = 0ull;
+    if (!first && !SMX_SKIP(a, 4)) {
       // broad phase over all env-mates first (circumscribed circles), narrow phase only over the
       // survivors: a wavefront then pays for max-over-lanes(candidates) box tests, not for n_veh
       unsigned long long cand = 0ull;
@@ -1145,15 +1554,18 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
         cand |= 1ull << j;
       }
       const double my_h = wrap_heading(s.heading);
-      while (cand != 0ull && !collided) {
+      // one Collision per collidee (smarts.py:1270-1291): every survivor is tested, not just the first hit
+      while (cand != 0ull) {
         const int j = __ffsll((long long)cand) - 1;
         cand &= cand - 1ull;
         const SharedPose& q = env_pose[j];
         if (boxes_within(px, py, my_h, q.x, q.y, q.heading, SMX_CHASSIS_LENGTH, SMX_CHASSIS_WIDTH,
                          SMX_COLLISION_LEEWAY))
-          collided = true;
+          collidee_mask |= 1ull << j;
       }
+      collided = collidee_mask != 0ull;
     }
+    if (o.collidees) o.collidees[gid] = collidee_mask;
 
     double lng, lat;
     long_lat_speed(s, trig, lng, lat);
@@ -1216,7 +1628,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
 
     // ---- neighbourhood (sensors.py:241-266, smarts.py:1191-1208): every other vehicle of the
     //      instance within `radius` (3-D distance), in slot order, first nb_max kept
-    if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !(a.debug_skip & 8)) {
+    if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !SMX_SKIP(a, 8)) {
       int cnt = 0;
       for (int j = 0; j < n_veh; ++j) {
         if (j == slot) continue;
@@ -1346,7 +1758,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
       } else {
         is_off_route = false;
         is_wrong_way = false;
-        if (!m.lane_in_junction[nl] && !(a.debug_skip & 64)) {
+        if (!m.lane_in_junction[nl] && !SMX_SKIP(a, 64)) {
           const double target = a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid];  // k_scan
           is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
         }
@@ -1863,6 +2275,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_grid_first(const KernelArgs a) {
   }
 }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_tables(const KernelArgs a) { waypoints_tables_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
 
@@ -1922,6 +2335,14 @@ struct smx_handle_s {
   MapDev map;
   void* map_blob;  // one device allocation holding every table
   size_t map_bytes;
+  void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
+  KnotLists knots;
+  // Large batches: the sensor kernels of a tick are independent of each other (they read the pose and write
+  // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
+  // their own write stream — so they are enqueued on side streams between two events and overlap.
+  hipStream_t side[2];
+  hipEvent_t ev_fork, ev_join[2];
+  bool side_ready;
   const double* lidar_rays;
   smx_via* vias_dev;
   int32_t* via_off_dev;
@@ -1929,6 +2350,7 @@ struct smx_handle_s {
   double heading_gain_pos, lateral_gain_pos;
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
+  int launch_strategy;  // SMX_LAUNCH_*
   bool timing;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2*i] start, [2*i+1] stop
   size_t ev_used;                   // pairs recorded since the last read
@@ -1937,6 +2359,8 @@ struct smx_handle_s {
   size_t ph_used;
   std::string err;
 };
+
+static thread_local std::string g_create_err;  // the reason of this thread's last failed smx_create
 
 static int fail(smx_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -1953,9 +2377,9 @@ extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; 
 
 #ifdef SMX_DEBUG_TIMING
 extern "C" int smx_prof_read(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
   if (reset) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(smx_prof), z, sizeof(z)) != hipSuccess) return -2;
   }
   return 0;
@@ -1987,9 +2411,7 @@ extern "C" uint64_t smx_struct_size(int which) {
   }
 }
 
-extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
-  if (!cfg || !out) return SMX_ERR_INVALID;
-  *out = nullptr;
+static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   smx_handle h = new (std::nothrow) smx_handle_s();
   if (!h) return SMX_ERR_NOMEM;
   h->cfg = *cfg;
@@ -1997,6 +2419,9 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->map_loaded = false;
   h->map_blob = nullptr;
   h->map_bytes = 0;
+  h->knots_blob = nullptr;
+  h->knots = KnotLists{nullptr, nullptr, nullptr, nullptr, nullptr};
+  h->side_ready = false;
   h->lidar_rays = nullptr;
   // lane_following_controller.py:426-430: place_poles gains clipped to [0.02, 0.04] / [3.4, 4.1];
   // for the sedan they saturate at (0.04, 3.4) for both Lane-space target speeds.
@@ -2009,10 +2434,11 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
   h->vias_dev = nullptr;
   h->via_off_dev = nullptr;
   h->n_vias = 0;
-  {
-    const char* dbg = getenv("SMX_DEBUG_SKIP");
-    h->debug_skip = dbg ? atoi(dbg) : 0;
-  }
+  h->launch_strategy = SMX_LAUNCH_AUTO;
+  h->debug_skip = 0;
+#ifdef SMX_DEBUG_TIMING
+  if (const char* dbg = getenv("SMX_DEBUG_SKIP")) h->debug_skip = atoi(dbg);
+#endif
   *out = h;
   const smx_config& c = h->cfg;
   if (c.num_envs <= 0 || c.num_vehicles <= 0 || c.num_vehicles > SMX_BLOCK)
@@ -2046,6 +2472,30 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
     return fail(h, SMX_ERR_INVALID, "neighbours: need 1 <= nb_max <= 127");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(h, SMX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return SMX_OK;
+}
+
+extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
+  if (out) *out = nullptr;
+  if (!cfg || !out) {
+    g_create_err = "smx_create: null config or handle pointer";
+    return SMX_ERR_INVALID;
+  }
+  smx_handle h = nullptr;
+  const int rc = create_impl(cfg, device, &h);
+  if (rc != SMX_OK) {  // no half-made handle for the caller to remember to destroy
+    g_create_err = h ? h->err : "out of memory";
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return SMX_OK;
+}
+
+extern "C" int smx_set_launch_strategy(smx_handle h, int strategy) {
+  if (!h) return SMX_ERR_INVALID;
+  if (strategy < SMX_LAUNCH_AUTO || strategy > SMX_LAUNCH_LARGE) return fail(h, SMX_ERR_INVALID, "unknown launch strategy");
+  h->launch_strategy = strategy;
   return SMX_OK;
 }
 
@@ -2152,6 +2602,29 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   PTR(sg_off, int32_t);
   PTR(sg_rec, smx_seg_rec);
 #undef PTR
+  // hand-off storage of the waypoints sensor's chain walks (the library's own: it never leaves the tick)
+  if ((h->cfg.sensors & SMX_SENSOR_WAYPOINTS) && !h->knots_blob) {
+    const size_t paths = (size_t)h->cfg.num_envs * h->cfg.num_vehicles * SMX_WP_LANES;
+    const size_t off_D = (size_t)(SMX_WPK_CAP + 1) * paths * sizeof(int32_t);
+    const size_t off_n = off_D + paths * sizeof(double), off_nk = off_n + paths * sizeof(int16_t);
+    const size_t off_cnt = off_nk + paths * sizeof(int16_t), bytes = off_cnt + paths;
+    SMX_HIP(hipMalloc(&h->knots_blob, bytes));
+    SMX_HIP(hipMemset(h->knots_blob, 0, bytes));
+    char* kb = (char*)h->knots_blob;
+    h->knots.idx = (int32_t*)kb;
+    h->knots.D = (double*)(kb + off_D);
+    h->knots.n = (int16_t*)(kb + off_n);
+    h->knots.nk = (int16_t*)(kb + off_nk);
+    h->knots.cnt = (uint8_t*)(kb + off_cnt);
+  }
+  if (!h->side_ready) {
+    for (int i = 0; i < 2; ++i) {
+      SMX_HIP(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+      SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    h->side_ready = true;
+  }
   h->map_loaded = true;
   return SMX_OK;
 }
@@ -2193,33 +2666,135 @@ extern "C" int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t 
   return SMX_OK;
 }
 
+// ---- entry check of every smx_reset / smx_step* (and smx_check_buffers, which needs no device) ----
+namespace {
+struct BufSpec {
+  const char* name;
+  const void* ptr;
+  uint64_t have;   // elements the caller declared
+  uint8_t dtype;   // SMX_DT_* the caller declared
+  uint64_t need;   // elements the configuration implies
+  uint8_t want;    // SMX_DT_* of the ABI
+  bool required;   // NULL is an error
+};
+const char* dtype_name(int d) {
+  static const char* n[] = {"none", "f64", "f32", "i32", "i16", "i8", "u8", "u64"};
+  return (d >= 0 && d <= SMX_DT_U64) ? n[d] : "?";
+}
+bool check_spec(const BufSpec& b, std::string& err) {
+  if (!b.ptr) {
+    if (!b.required) return true;
+    err = std::string(b.name) + " is NULL but the configuration needs it";
+    return false;
+  }
+  if (b.dtype != b.want) {
+    err = std::string(b.name) + ": declared dtype " + dtype_name(b.dtype) + ", the ABI says " + dtype_name(b.want);
+    return false;
+  }
+  if (b.have < b.need) {
+    err = std::string(b.name) + ": " + std::to_string(b.have) + " elements declared, the configuration needs " +
+          std::to_string(b.need) + " (a short buffer would be an out-of-bounds device write)";
+    return false;
+  }
+  return true;
+}
+}  // namespace
+
+static int check_buffers_impl(const smx_config& c, bool has_vias, bool need_lidar_rays_set, const smx_state* st,
+                              const smx_spawns* sp, const smx_outputs* o, std::string& err) {
+  if (!st || !sp || !o) {
+    err = "null state / spawns / outputs";
+    return SMX_ERR_INVALID;
+  }
+  (void)need_lidar_rays_set;
+  const uint64_t E = (uint64_t)c.num_envs, T = E * (uint64_t)c.num_vehicles;
+  const bool wp = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0, nb = (c.sensors & SMX_SENSOR_NEIGHBORS) != 0;
+  const bool ogm = (c.sensors & SMX_SENSOR_OGM) != 0, dagm = (c.sensors & SMX_SENSOR_DAGM) != 0;
+  const bool lidar = (c.sensors & SMX_SENSOR_LIDAR) != 0, vias = c.via_max > 0 && has_vias;
+  const uint64_t PW = (uint64_t)c.wp_paths * c.wp_len, K = (uint64_t)c.nb_max, R = (uint64_t)c.lidar_rays;
+#define ST(field, idx, need, want, req) \
+  {"state." #field, st->field, st->count[idx], st->dtype[idx], (uint64_t)(need), want, req}
+#define OUT(field, idx, need, want, req) \
+  {"out." #field, o->field, o->count[idx], o->dtype[idx], (uint64_t)(need), want, req}
+  const BufSpec specs[] = {
+      ST(f64, SMX_ST_F64, SMX_S_COUNT * T, SMX_DT_F64, true),
+      ST(flags, SMX_ST_FLAGS, T, SMX_DT_I32, true),
+      ST(steps, SMX_ST_STEPS, T, SMX_DT_I32, true),
+      ST(env_ticks, SMX_ST_ENV_TICKS, E, SMX_DT_I32, true),
+      ST(env_done_count, SMX_ST_ENV_DONE_COUNT, E, SMX_DT_I32, true),
+      ST(env_episode, SMX_ST_ENV_EPISODE, E, SMX_DT_I32, true),
+      ST(driven_path, SMX_ST_DRIVEN_PATH, T * SMX_DRIVEN_PATH_LEN, SMX_DT_F64, (c.done_criteria & SMX_DONE_NOT_MOVING) != 0),
+      ST(seed_cache, SMX_ST_SEED_CACHE, SMX_SEED_COUNT * T, SMX_DT_I32, true),
+      ST(facts_i32, SMX_ST_FACTS_I32, SMX_FACT_I_COUNT * T, SMX_DT_I32, true),
+      ST(facts_f64, SMX_ST_FACTS_F64, SMX_FACT_F_COUNT * T, SMX_DT_F64, true),
+      ST(env_reset_pending, SMX_ST_ENV_RESET_PENDING, E, SMX_DT_I32, true),
+      {"spawns.pose", sp->pose, sp->pose_count, SMX_DT_F64, (uint64_t)(sp->episodes > 0 ? sp->episodes : 0) * T * 4, SMX_DT_F64, true},
+      {"spawns.social", sp->social, sp->social_count, SMX_DT_F64, (uint64_t)(sp->episodes > 0 ? sp->episodes : 0) * T * 2, SMX_DT_F64,
+       c.num_social > 0},
+      OUT(ego_pos, SMX_OUT_EGO_POS, 3 * T, SMX_DT_F64, true),
+      OUT(ego_f32, SMX_OUT_EGO_F32, SMX_EGO_F32_COUNT * T, SMX_DT_F32, true),
+      OUT(ego_lane, SMX_OUT_EGO_LANE, 2 * T, SMX_DT_I16, true),
+      OUT(events, SMX_OUT_EVENTS, SMX_EV_COUNT * T, SMX_DT_U8, true),
+      OUT(reward, SMX_OUT_REWARD, T, SMX_DT_F64, true),
+      OUT(dist, SMX_OUT_DIST, T, SMX_DT_F64, true),
+      OUT(done, SMX_OUT_DONE, T, SMX_DT_U8, true),
+      OUT(active, SMX_OUT_ACTIVE, T, SMX_DT_U8, true),
+      OUT(env_done, SMX_OUT_ENV_DONE, E, SMX_DT_U8, true),
+      OUT(via_near, SMX_OUT_VIA_NEAR, T * (uint64_t)(c.via_max > 0 ? c.via_max : 0), SMX_DT_I8, vias),
+      OUT(via_near_count, SMX_OUT_VIA_NEAR_COUNT, T, SMX_DT_U8, vias),
+      OUT(via_hit, SMX_OUT_VIA_HIT, T, SMX_DT_I32, vias),
+      OUT(learner, SMX_OUT_LEARNER, 2 * T, SMX_DT_F32, false),
+      OUT(wp_pos, SMX_OUT_WP_POS, T * PW * 3, SMX_DT_F64, wp),
+      OUT(wp_heading, SMX_OUT_WP_HEADING, T * PW, SMX_DT_F32, wp),
+      OUT(wp_lane_width, SMX_OUT_WP_LANE_WIDTH, T * PW, SMX_DT_F32, wp),
+      OUT(wp_speed_limit, SMX_OUT_WP_SPEED_LIMIT, T * PW, SMX_DT_F32, wp),
+      OUT(wp_lane_index, SMX_OUT_WP_LANE_INDEX, T * PW, SMX_DT_I8, wp),
+      OUT(wp_lane_id, SMX_OUT_WP_LANE_ID, T * PW, SMX_DT_I16, wp),
+      OUT(wp_count, SMX_OUT_WP_COUNT, T * (uint64_t)(c.wp_paths + 1), SMX_DT_U8, wp),
+      OUT(nb_pos, SMX_OUT_NB_POS, T * K * 3, SMX_DT_F64, nb),
+      OUT(nb_box, SMX_OUT_NB_BOX, T * K * 3, SMX_DT_F32, nb),
+      OUT(nb_heading, SMX_OUT_NB_HEADING, T * K, SMX_DT_F32, nb),
+      OUT(nb_speed, SMX_OUT_NB_SPEED, T * K, SMX_DT_F32, nb),
+      OUT(nb_lane_index, SMX_OUT_NB_LANE_INDEX, T * K, SMX_DT_I8, nb),
+      OUT(nb_lane_id, SMX_OUT_NB_LANE_ID, T * K, SMX_DT_I16, nb),
+      OUT(nb_slot, SMX_OUT_NB_SLOT, T * K, SMX_DT_I8, nb),
+      OUT(nb_count, SMX_OUT_NB_COUNT, T, SMX_DT_U8, nb),
+      OUT(ogm, SMX_OUT_OGM, T * (uint64_t)c.ogm_width * c.ogm_height, SMX_DT_U8, ogm),
+      OUT(lidar_hit, SMX_OUT_LIDAR_HIT, T * R, SMX_DT_U8, lidar),
+      OUT(lidar_point, SMX_OUT_LIDAR_POINT, T * R * 3, SMX_DT_F64, lidar),
+      OUT(dagm, SMX_OUT_DAGM, T * (uint64_t)c.dagm_width * c.dagm_height, SMX_DT_U8, dagm),
+      OUT(collidees, SMX_OUT_COLLIDEES, T, SMX_DT_U64, false),
+  };
+#undef ST
+#undef OUT
+  if (sp->episodes < 1) {
+    err = "spawn table is empty (episodes < 1)";
+    return SMX_ERR_INVALID;
+  }
+  for (const BufSpec& b : specs)
+    if (!check_spec(b, err)) return SMX_ERR_INVALID;
+  return SMX_OK;
+}
+
+extern "C" int smx_check_buffers(const smx_config* cfg, int has_vias, const smx_state* st, const smx_spawns* sp,
+                                 const smx_outputs* out, char* err, uint64_t err_len) {
+  std::string msg;
+  int rc = cfg ? check_buffers_impl(*cfg, has_vias != 0, false, st, sp, out, msg) : SMX_ERR_INVALID;
+  if (!cfg) msg = "null config";
+  if (err && err_len > 0) {
+    const size_t n = std::min<size_t>(msg.size(), (size_t)err_len - 1);
+    memcpy(err, msg.data(), n);
+    err[n] = 0;
+  }
+  return rc;
+}
+
 static int check_buffers(smx_handle h, const smx_state* st, const smx_spawns* sp, const smx_outputs* o) {
-  if (!st || !sp || !o) return fail(h, SMX_ERR_INVALID, "null state / spawns / outputs");
-  if (!st->f64 || !st->flags || !st->steps || !st->env_ticks || !st->env_done_count || !st->env_episode ||
-      !st->seed_cache || !st->facts_i32 || !st->facts_f64 || !st->env_reset_pending)
-    return fail(h, SMX_ERR_INVALID, "null state buffer");
-  if (!sp->pose || sp->episodes < 1) return fail(h, SMX_ERR_INVALID, "spawn table is empty");
-  if (h->cfg.num_social > 0 && !sp->social) return fail(h, SMX_ERR_INVALID, "num_social > 0 needs smx_spawns.social");
-  if (!o->ego_pos || !o->ego_f32 || !o->ego_lane || !o->events || !o->reward || !o->dist || !o->done || !o->active ||
-      !o->env_done)
-    return fail(h, SMX_ERR_INVALID, "null output buffer");
-  const smx_config& c = h->cfg;
-  if ((c.sensors & SMX_SENSOR_WAYPOINTS) && (!o->wp_pos || !o->wp_heading || !o->wp_lane_width || !o->wp_speed_limit ||
-                                             !o->wp_lane_index || !o->wp_lane_id || !o->wp_count))
-    return fail(h, SMX_ERR_INVALID, "waypoints sensor enabled but an output buffer is null");
-  if ((c.sensors & SMX_SENSOR_NEIGHBORS) && (!o->nb_pos || !o->nb_box || !o->nb_heading || !o->nb_speed ||
-                                             !o->nb_lane_index || !o->nb_lane_id || !o->nb_slot || !o->nb_count))
-    return fail(h, SMX_ERR_INVALID, "neighbourhood sensor enabled but an output buffer is null");
-  if (c.via_max > 0 && h->n_vias > 0 && (!o->via_near || !o->via_near_count || !o->via_hit))
-    return fail(h, SMX_ERR_INVALID, "vias are set but a via output buffer is null");
-  if ((c.sensors & SMX_SENSOR_OGM) && !o->ogm) return fail(h, SMX_ERR_INVALID, "ogm sensor enabled but out.ogm is null");
-  if ((c.sensors & SMX_SENSOR_DAGM) && !o->dagm) return fail(h, SMX_ERR_INVALID, "dagm sensor enabled but out.dagm is null");
-  if ((c.sensors & SMX_SENSOR_LIDAR) && (!o->lidar_hit || !o->lidar_point))
-    return fail(h, SMX_ERR_INVALID, "lidar sensor enabled but an output buffer is null");
-  if ((c.sensors & SMX_SENSOR_LIDAR) && !h->lidar_rays)
+  std::string msg;
+  const int rc = check_buffers_impl(h->cfg, h->n_vias > 0, true, st, sp, o, msg);
+  if (rc != SMX_OK) return fail(h, rc, msg);
+  if ((h->cfg.sensors & SMX_SENSOR_LIDAR) && !h->lidar_rays)
     return fail(h, SMX_ERR_STATE, "lidar sensor enabled but smx_set_lidar_rays has not been called");
-  if ((c.done_criteria & SMX_DONE_NOT_MOVING) && !st->driven_path)
-    return fail(h, SMX_ERR_INVALID, "not_moving done criterion needs the driven_path ring");
   return SMX_OK;
 }
 
@@ -2262,14 +2837,16 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.heading_gain_pos = h->heading_gain_pos;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
+  a.knots = h->knots;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
   // Small batches are bound by one wavefront's latency, so independent work is spread over more
   // workgroups (k_scan halves as separate roles: 54 vs 70 us at 8 k vehicles; the OGM role inside
   // k_sensors); large batches are bound by throughput, where the same tricks cost occupancy
   // (131 k vehicles: k_scan 0.69 vs 0.52 ms split vs back-to-back, OGM inside k_sensors +6 %).
-  const bool small_batch = (total <= 32768) || (h->debug_skip & 131072);
-  const int scan_split = (small_batch || (h->debug_skip & 65536)) ? 1 : 0;
+  const bool small_batch = h->launch_strategy == SMX_LAUNCH_SMALL ||
+                           (h->launch_strategy == SMX_LAUNCH_AUTO && total <= 32768) || SMX_SKIP(*h, 131072);
+  const int scan_split = (small_batch || SMX_SKIP(*h, 65536)) ? 1 : 0;
   const int scan_blocks = (scan_split ? 2 : 1) * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
   const int vpb = SMX_BLOCK / SMX_WP_LANES;
   const int wp_blocks = (int)((total + vpb - 1) / vpb);
@@ -2322,22 +2899,45 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     else
       hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
-    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
-    if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, k);
+    // large batches, no per-kernel timing asked: grid maps on side stream 0, observe (+ lidar) on side stream 1,
+    // waypoints on the caller's stream, joined before k_commit
+    const bool fork = !small_batch && !phased && h->side_ready;
+    hipStream_t s_grid = stream, s_obs = stream;
+    if (fork) {
+      (void)hipEventRecord(h->ev_fork, stream);
+      (void)hipStreamWaitEvent(h->side[0], h->ev_fork, 0);
+      (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
+      s_grid = h->side[0];
+      s_obs = h->side[1];
+    }
+    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, s_grid, k);
+    if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_OGM + 1], stream);
     if (small_batch) {
       hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, k);
     } else {
-      hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, k);
-      hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
-      if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      // staged rows whenever the waypoints sensor is on and the rows fit that form
+      if ((c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS && h->knots_blob) {
+        hipLaunchKernelGGL(k_wp_walk, dim3((unsigned)((total * SMX_WP_LANES + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0, stream, k);
+        const size_t stage_bytes = std::max((size_t)c.wp_len * SMX_BLOCK * 16, (size_t)SMX_MAX_KNOTS * SMX_BLOCK * sizeof(int));
+        hipLaunchKernelGGL(k_waypoints_tables, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, k);
+      } else
+        hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+      if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+    }
+    if (fork) {
+      for (int i = 0; i < 2; ++i) {
+        (void)hipEventRecord(h->ev_join[i], h->side[i]);
+        (void)hipStreamWaitEvent(stream, h->ev_join[i], 0);
+      }
     }
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SENSORS + 1], stream);
     hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_COMMIT + 1], stream);
   };
   // the LDS-path form of k_control fits one wavefront per SIMD: only while the batch needs no more
-  const bool lds_path = total * SMX_WP_LANES <= (size_t)1024 * 64;
+  const bool lds_path = h->launch_strategy == SMX_LAUNCH_AUTO ? total * SMX_WP_LANES <= (size_t)1024 * 64 : small_batch;
   if (is_step && c.num_social > 0 && c.social_model == SMX_SOCIAL_IDM)
     hipLaunchKernelGGL(k_social, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
   if (is_step) {
@@ -2472,11 +3072,20 @@ extern "C" int smx_last_step_ms(smx_handle h, float* ms) {
   return SMX_OK;
 }
 
-extern "C" const char* smx_last_error(smx_handle h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" const char* smx_last_error(smx_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
+  if (h->knots_blob) (void)hipFree(h->knots_blob);
+  if (h->side_ready) {
+    for (int i = 0; i < 2; ++i) {
+      (void)hipStreamSynchronize(h->side[i]);
+      (void)hipStreamDestroy(h->side[i]);
+      (void)hipEventDestroy(h->ev_join[i]);
+    }
+    (void)hipEventDestroy(h->ev_fork);
+  }
   if (h->vias_dev) (void)hipFree(h->vias_dev);
   if (h->via_off_dev) (void)hipFree(h->via_off_dev);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

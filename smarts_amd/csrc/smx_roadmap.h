@@ -507,41 +507,13 @@ struct WaypointOut {
 // records (independent loads) and emits the waypoints t_i = i * D / (n - 1) by np.interp's rule
 // (knot j = last knot with cum[j] <= t; exact knot value when t == cum[j]) while lane_id /
 // lane_index follow the "last knot strictly passed" rule of :1404-1417.
-template <class Emit>
-__device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f, BranchState& bs, int start,
-                                          int lookahead, double px, double py, int* knots, int kstride,
-                                          int max_emit, Emit&& emit) {
-  KnotWalk w;
-  w.begin(m, start, lookahead);
-  const smx_lp_rec r0 = w.cur;
-  // ---- knot 0: projection of the query point on the first lanepoint's heading line
-  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
-  const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
-
-  // ---- pass 1
-  SMX_TSTAMP(te0);
-  int nk = 0;
-  double D = 0.0;
-  {
-    double lastx = k0x, lasty = k0y;
-    smx_lp_rec rec;
-    bool last = false;
-    for (;;) {
-      int idx = w.next(m, f, bs, rec, last);
-      if (idx < 0) break;
-      if (nk < SMX_MAX_KNOTS) knots[nk * kstride] = idx;
-      (void)SMX_BCHK(16, nk, SMX_MAX_KNOTS);
-      ++nk;
-      double ex = rec.x - lastx, ey = rec.y - lasty;
-      D += sqrt(ex * ex + ey * ey);
-      lastx = rec.x;
-      lasty = rec.y;
-    }
-  }
-  const int n = w.n;
+// Pass 2: the waypoints of a path whose knots are known — `fetch(k)` gives the lanepoint index of knot
+// k = 0..nk-1 in path order (r0 = the start lanepoint's record, n = lanepoints on the path, D = the knot
+// arclength).  emit(i, wp) is called for i < min(n, max_emit).
+template <class Fetch, class Emit>
+__device__ inline void interpolate_knots(const MapDev& m, const smx_lp_rec& r0, int nk, int n, double D, double px,
+                                         double py, int max_emit, Fetch&& fetch, Emit&& emit) {
   const int lane0 = r0.lane;
-  SMX_TSTAMP(te1);
-  SMX_TACC(4, te0, te1);
   if (n == 1) {
     // :1379-1390 (a one-point path): the lanepoint itself, not the projection
     if (max_emit > 0) {
@@ -554,12 +526,13 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
       o.lane = lane0;
       emit(0, o);
     }
-    return 1;
+    return;
   }
-
-  // ---- pass 2: emit
   const int n_emit = min(n, max_emit);
-  if (n_emit <= 0) return n;
+  if (n_emit <= 0) return;
+  // ---- knot 0: projection of the query point on the first lanepoint's heading line
+  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+  const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
   const double step = D / (double)(n - 1);  // np.linspace(0, D, n)
   int i = 0;                                // next waypoint to emit
   double t = 0.0;
@@ -568,13 +541,13 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
   int strict_lane = lane0;  // lane of the last knot with cum strictly below jcum (knot 0 if none)
   Unwrap uw;
   uw.start(jh);
-  smx_lp_rec q = (nk > 0) ? load_lp(m, knots[0], 44) : r0;
+  smx_lp_rec q = (nk > 0) ? load_lp(m, fetch(0), 44) : r0;
   // width / speed limit of knot j's lane, carried from knot to knot: most knots share their lane,
   // and a table look-up per knot would put a dependent load in front of every segment
   double wj = m.lane_width[SMX_BCHK(18, jlane, m.n_lanes)], sj = m.lane_speed[jlane];
   for (int k = 0; k < nk && i < n_emit; ++k) {
     const smx_lp_rec cur = q;
-    if (k + 1 < nk) q = load_lp(m, knots[(k + 1) * kstride], 45);  // prefetch the next knot
+    if (k + 1 < nk) q = load_lp(m, fetch(k + 1), 45);  // prefetch the next knot
     const double qx = cur.x, qy = cur.y;
     const double ex = qx - jx, ey = qy - jy;
     const double qcum = jcum + sqrt(ex * ex + ey * ey);
@@ -635,9 +608,96 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     ++i;
     t = (i == n - 1) ? D : (double)i * step;
   }
+}
+
+template <class Emit>
+__device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f, BranchState& bs, int start,
+                                          int lookahead, double px, double py, int* knots, int kstride,
+                                          int max_emit, Emit&& emit) {
+  KnotWalk w;
+  w.begin(m, start, lookahead);
+  const smx_lp_rec r0 = w.cur;
+  // ---- knot 0: projection of the query point on the first lanepoint's heading line
+  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+  const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
+
+  // ---- pass 1
+  SMX_TSTAMP(te0);
+  int nk = 0;
+  double D = 0.0;
+  {
+    double lastx = k0x, lasty = k0y;
+    smx_lp_rec rec;
+    bool last = false;
+    for (;;) {
+      int idx = w.next(m, f, bs, rec, last);
+      if (idx < 0) break;
+      if (nk < SMX_MAX_KNOTS) knots[nk * kstride] = idx;
+      (void)SMX_BCHK(16, nk, SMX_MAX_KNOTS);
+      ++nk;
+      double ex = rec.x - lastx, ey = rec.y - lasty;
+      D += sqrt(ex * ex + ey * ey);
+      lastx = rec.x;
+      lasty = rec.y;
+    }
+  }
+  const int n = w.n;
+  SMX_TSTAMP(te1);
+  SMX_TACC(4, te0, te1);
+  // ---- pass 2: emit
+  interpolate_knots(m, r0, nk, n, D, px, py, max_emit, [&](int k) { return knots[k * kstride]; }, emit);
   SMX_TSTAMP(te2);
   SMX_TACC(5, te1, te2);
   return n;
+}
+
+// ---------------------------------------------------------------------------------
+// Knot lists: the chain walk of a path, split from its interpolation.
+// ---------------------------------------------------------------------------------
+// Knot lists: what the chain walk (one lane per path, dependent loads) leaves in device memory for the
+// kernels that need the path's knots afterwards — they re-read the records with independent loads.
+// Layout [entry][path] (path = vehicle * 4 + seed lane), so a wavefront's store of entry k is contiguous.
+#define SMX_WPK_CAP 20  // entries kept per path: entry 0 = the start lanepoint, then the knots in path order
+struct KnotLists {
+  int32_t* idx;   // [SMX_WPK_CAP + 1][paths]
+  double* D;      // [paths] arclength over all knots, from the projection of the query point
+  int16_t* n;     // [paths] lanepoints on the path; 0 = the seed lane starts no path
+  int16_t* nk;    // [paths] knots after the start
+  uint8_t* cnt;   // [paths] paths that start on this seed lane (1 unless the walk meets a branching)
+};
+
+struct PathWalk {
+  int n;     // lanepoints on the path
+  int nk;    // knots after entry 0
+  double D;  // arclength over all knots
+};
+
+// Pass 1 of equally_spaced_path: sink(k, lanepoint index) is called for every knot k = 1..nk in path order.
+template <class Sink>
+__device__ inline PathWalk walk_knots(const MapDev& m, const RouteFilter& f, BranchState& bs, int start, int lookahead,
+                                      double px, double py, Sink&& sink) {
+  KnotWalk w;
+  w.begin(m, start, lookahead);
+  const smx_lp_rec r0 = w.cur;
+  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+  PathWalk out;
+  out.nk = 0;
+  out.D = 0.0;
+  double lastx = r0.x + proj * r0.dirx, lasty = r0.y + proj * r0.diry;
+  smx_lp_rec rec;
+  bool last = false;
+  for (;;) {
+    const int idx = w.next(m, f, bs, rec, last);
+    if (idx < 0) break;
+    ++out.nk;
+    const double ex = rec.x - lastx, ey = rec.y - lasty;
+    out.D += sqrt(ex * ex + ey * ey);
+    lastx = rec.x;
+    lasty = rec.y;
+    sink(out.nk, idx);
+  }
+  out.n = w.n;
+  return out;
 }
 
 // ---------------------------------------------------------------------------------

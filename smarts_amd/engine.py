@@ -65,6 +65,7 @@ class SimConfig:
     social_speed_factor: float = 0.8
     social_model: str = "constant"  # "constant" | "idm" (include/smx.h SMX_SOCIAL_*)
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
+    launch_strategy: str = "auto"  # "auto" | "small" | "large": how a tick is cut into launches (include/smx.h)
 
     def sensors_mask(self) -> int:
         m = 0
@@ -265,6 +266,8 @@ class BatchedSim:
         self.handle = C.c_void_p()
         rc = self.lib.smx_create(C.byref(c), idx, C.byref(self.handle))
         nat.check(self.lib, self.handle, rc, "smx_create")
+        rc = self.lib.smx_set_launch_strategy(self.handle, nat.LAUNCH_STRATEGIES[cfg.launch_strategy])
+        nat.check(self.lib, self.handle, rc, "smx_set_launch_strategy")
         tables, keep = map_tables_struct(cm)
         nat.check(self.lib, self.handle, self.lib.smx_load_map(self.handle, C.byref(tables)), "smx_load_map")
         del keep
@@ -293,18 +296,17 @@ class BatchedSim:
         self.env_episode = torch.full((E,), -1, dtype=torch.int32, device=dev)
         need_ring = cfg.track_driven_path or cfg.done_not_moving
         self.driven_path = torch.zeros((T, nat.DRIVEN_PATH_LEN), dtype=torch.float64, device=dev) if need_ring else None
-        st = nat.SmxState()
-        st.f64, st.flags, st.steps = self.state.data_ptr(), self.flags.data_ptr(), self.steps.data_ptr()
-        st.env_ticks, st.env_done_count = self.env_ticks.data_ptr(), self.env_done_count.data_ptr()
-        st.env_episode = self.env_episode.data_ptr()
-        st.driven_path = self.driven_path.data_ptr() if need_ring else None
         self.seed_cache = torch.full((nat.SEED_COUNT, E, N), -1, dtype=torch.int32, device=dev)
-        st.seed_cache = self.seed_cache.data_ptr()
         self.facts_i32 = torch.full((nat.FACT_I_COUNT, E, N), -1, dtype=torch.int32, device=dev)
         self.facts_f64 = torch.zeros((nat.FACT_F_COUNT, E, N), dtype=torch.float64, device=dev)
         self.env_reset_pending = torch.zeros((E,), dtype=torch.int32, device=dev)
-        st.facts_i32, st.facts_f64 = self.facts_i32.data_ptr(), self.facts_f64.data_ptr()
-        st.env_reset_pending = self.env_reset_pending.data_ptr()
+        st = nat.SmxState()
+        for name, t in (("f64", self.state), ("flags", self.flags), ("steps", self.steps), ("env_ticks", self.env_ticks),
+                        ("env_done_count", self.env_done_count), ("env_episode", self.env_episode),
+                        ("driven_path", self.driven_path), ("seed_cache", self.seed_cache),
+                        ("facts_i32", self.facts_i32), ("facts_f64", self.facts_f64),
+                        ("env_reset_pending", self.env_reset_pending)):
+            nat.bind_buffer(st, nat.STATE_BUFFERS, name, t)  # pointer + element count + dtype (checked on entry)
         self._st = st
 
         # ---- spawns ----
@@ -317,7 +319,7 @@ class BatchedSim:
         assert spawns.ndim == 3 and spawns.shape[1:] == (T, 4), spawns.shape
         self.spawns = torch.from_numpy(spawns).to(dev)
         sp = nat.SmxSpawns()
-        sp.episodes, sp.pose = int(spawns.shape[0]), self.spawns.data_ptr()
+        sp.episodes, sp.pose, sp.pose_count = int(spawns.shape[0]), self.spawns.data_ptr(), self.spawns.numel()
         self.social_spawns = None
         if cfg.num_social > 0:
             if social_spawns is None:
@@ -326,7 +328,7 @@ class BatchedSim:
             social_spawns = np.ascontiguousarray(social_spawns, dtype=np.float64)
             assert social_spawns.shape == (spawns.shape[0], T, 2), social_spawns.shape
             self.social_spawns = torch.from_numpy(social_spawns).to(dev)
-            sp.social = self.social_spawns.data_ptr()
+            sp.social, sp.social_count = self.social_spawns.data_ptr(), self.social_spawns.numel()
         self._sp = sp
 
         # ---- outputs (dense StdObs layout, format_obs.py:313-373) ----
@@ -378,9 +380,10 @@ class BatchedSim:
         self._learner_k = 0
         o["learner"] = self._learner[0]
         self.out = o
+        o["collidees"] = z((E, N), torch.int64)  # bit j: touching the vehicle in slot j (read as unsigned)
         so = nat.SmxOutputs()
         for name in nat.OUTPUT_FIELDS:
-            setattr(so, name, o[name].data_ptr() if name in o else None)
+            nat.bind_buffer(so, nat.OUTPUT_FIELDS, name, o.get(name))
         self._out = so
         self._stream = None
         self._was_reset = False
@@ -401,36 +404,41 @@ class BatchedSim:
     def state_bytes_per_agent_step(self) -> int:
         return nat.S_COUNT * 8 + 4 + 4 + nat.SEED_COUNT * 4
 
-    def kernel_bytes_per_agent_step(self) -> Dict[str, int]:
-        """Algorithmic HBM bytes of one agent-step, attributed to the kernel that must move them
-        (DESIGN.md "Kernels"): compulsory reads of per-vehicle state/action plus every output byte,
-        map tables (L2/LDS resident) not counted — SURVEY.md §8(d)'s accounting on this layout."""
+    def kernel_bytes_per_agent_step(self) -> Dict[str, Tuple[int, int]]:
+        """Algorithmic HBM bytes of one agent-step as (read, write) per timing phase — SURVEY.md §8(d)'s
+        accounting on this layout: compulsory reads of the vehicle's own state and action, the state written
+        back, and every observation / reward / done byte of the dense rows.  NOT counted: the map tables
+        (L2 / Infinity-Cache resident) and the hand-off buffers between the kernels of a tick (path seeds,
+        road facts: ``handoff_bytes_per_agent_step``) — traffic this design adds, not traffic the path needs."""
         o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items() if k not in ("env_done", "learner")}
-        o["learner_block"] = 8  # reward + done as float32
-        seeds, facts = nat.SEED_COUNT * 4, nat.FACT_I_COUNT * 4 + nat.FACT_F_COUNT * 8
-        state = nat.S_COUNT * 8 + 4 + 4
+        pose = 3 * 8 + 4  # x, y, heading + flags: what every sensor kernel reads of a vehicle
+        ctrl_state = 14 * 8 + 4  # SMX_S_X .. SMX_S_MCL_Y + flags: read and written back by k_control
+        obs_state_r, obs_state_w = 16 * 8 + 4 + 4, 12 * 8 + 4  # trip meter / accelerometer / driven-path fields, steps
+        wp = sum(v for k, v in o.items() if k.startswith("wp_")) if self.cfg.waypoints else 0
+        rows = sum(v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar", "dagm"))) + 8  # + learner block
         kb = {
-            # state read + write, action, last tick's seeds
-            "control": 2 * state + 1 + seeds,
-            # pose read, facts + seeds written
-            "scan": 3 * 8 + 4 + facts + seeds,
-            # pose + seeds read, waypoint rows written
-            "waypoints": (3 * 8 + 4 + seeds + sum(v for k, v in o.items() if k.startswith("wp_"))) if self.cfg.waypoints else 0,
-            # state + facts read, trip/accelerometer state written back, ego/neighbour/event/reward rows written
-            "observe": state + facts + 12 * 8 + sum(
-                v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar", "dagm"))),
+            "control": (ctrl_state + (12 if self.cfg.action_space != "Lane" else 1), ctrl_state + 2 * 8),
+            "scan": (pose, 0),
+            "sensors": ((pose if self.cfg.waypoints else 0) + obs_state_r, wp + rows + obs_state_w),
+            "commit": (4, 4),
         }
-        ogm = (3 * 8 + 4 + o["ogm"]) if self.cfg.ogm else 0
-        dagm = (3 * 8 + 4 + o["dagm"]) if self.cfg.dagm else 0  # map segments are L2-resident, not counted
+        ogm = (pose, o["ogm"]) if self.cfg.ogm else (0, 0)
+        dagm = (pose, o["dagm"]) if self.cfg.dagm else (0, 0)
         ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
                       and self.E * self.N <= 32768)  # smx_kernels.hip enqueue(): small batches only
+        add = lambda a, b: (a[0] + b[0], a[1] + b[1])  # noqa: E731
         if (self.cfg.ogm and not ogm_inline) or self.cfg.dagm:
-            kb["ogm"] = (0 if ogm_inline else ogm) + dagm  # their own launches (one timing phase)
-        lidar = (3 * 8 + 4 + o["lidar_hit"] + o["lidar_point"]) if self.cfg.lidar is not None else 0
-        # k_sensors runs the waypoints, observe and lidar roles in one launch; k_commit applies the flags
-        kb["sensors"] = kb.pop("waypoints") + kb.pop("observe") + lidar + (ogm if ogm_inline else 0)
-        kb["commit"] = 3 * 4
+            kb["ogm"] = add((0, 0) if ogm_inline else ogm, dagm)  # their own launches (one timing phase)
+        if ogm_inline:
+            kb["sensors"] = add(kb["sensors"], ogm)
+        if self.cfg.lidar is not None:
+            kb["sensors"] = add(kb["sensors"], (pose, o["lidar_hit"] + o["lidar_point"]))
         return kb
+
+    def handoff_bytes_per_agent_step(self) -> int:
+        """Bytes written by one kernel of the tick and read by a later one (path seeds, road facts, next flags):
+        reported beside the algorithmic bytes, never inside them."""
+        return 2 * (nat.SEED_COUNT * 4 + nat.FACT_I_COUNT * 4 + nat.FACT_F_COUNT * 8) + nat.SEED_COUNT * 4
 
     def reset(self, env_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         mask_ptr = None
@@ -449,7 +457,7 @@ class BatchedSim:
             raise RuntimeError("step() before reset()")  # SMARTSNotSetupError (smarts.py:207-208)
         self._learner_k ^= 1
         self.out["learner"] = self._learner[self._learner_k]
-        self._out.learner = self.out["learner"].data_ptr()
+        self._out.learner = self.out["learner"].data_ptr()  # same extent and dtype as the other block
         if self.cfg.action_space == "Trajectory":
             raise ValueError("ActionSpaceType.Trajectory steps through step_trajectory(trajectories, counts)")
         if self.cfg.action_space == "Lane":

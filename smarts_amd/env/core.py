@@ -170,15 +170,18 @@ class BatchCore:
             lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias)
         self._was_reset = False
         self._destroyed = False
-        self.step_count = np.zeros(num_envs, dtype=np.int64)
+
+    @property
+    def step_count(self) -> np.ndarray:
+        """Ticks since each env's last reset, read from the device (``smx_state.env_ticks``): the one clock
+        of the batch, also across ``reset_dense(env_mask)`` and the in-launch auto-reset."""
+        return self.sim.env_ticks.cpu().numpy().astype(np.int64)
 
     # ------------------------------------------------------------------ dense (fast) path
     def reset_dense(self, env_mask=None):
         self._check_alive()
         out = self.sim.reset(env_mask)
         self._was_reset = True
-        if env_mask is None:
-            self.step_count[:] = self.cfg.reset_elapsed_steps()
         return out
 
     def step_dense(self, actions):
@@ -186,9 +189,7 @@ class BatchCore:
         self._check_alive()
         if not self._was_reset:
             raise SMARTSNotSetupError("Must call reset() or setup() before stepping.")
-        out = self.sim.step(actions)
-        self.step_count += 1
-        return out
+        return self.sim.step(actions)
 
     # ------------------------------------------------------------------ object path
     def step_actions(self, per_env_actions: Sequence[Dict[str, Any]]):
@@ -217,9 +218,7 @@ class BatchCore:
         self._check_alive()
         if not self._was_reset:
             raise SMARTSNotSetupError("Must call reset() or setup() before stepping.")
-        out = self.sim.step_trajectory(torch.from_numpy(packed), torch.from_numpy(counts))
-        self.step_count += 1
-        return out
+        return self.sim.step_trajectory(torch.from_numpy(packed), torch.from_numpy(counts))
 
     def encode_actions(self, per_env_actions: Sequence[Dict[str, Any]]) -> np.ndarray:
         space = self.interface.action
@@ -249,11 +248,16 @@ class BatchCore:
         import torch
 
         torch.cuda.synchronize(self.sim.device)
-        return {k: v.cpu().numpy() for k, v in out.items()}
+        # the learner block is [2, E, N] (reward / done axis first) and exists for the device-side gather only
+        rows = {k: v.cpu().numpy() for k, v in out.items() if k != "learner"}
+        rows["env_ticks"] = self.sim.env_ticks.cpu().numpy()
+        return rows
+
+    PER_ENV_ROWS = ("env_done", "env_ticks")  # [E]; every other row is [E, N, ...]
 
     def observations(self, rows: Dict[str, np.ndarray], env: int, present: np.ndarray) -> Dict[str, Observation]:
-        er = {k: v[env] for k, v in rows.items() if k != "env_done"}
-        t = int(self.step_count[env])
+        er = {k: v[env] for k, v in rows.items() if k not in self.PER_ENV_ROWS}
+        t = int(rows["env_ticks"][env])  # device clock: already that of the new episode after an auto-reset
         elapsed = round(t * self.dt, 6)
         return {self.agent_ids[i]: self.builder.build(er, i, t, elapsed) for i in range(self.N) if present[i]}
 

@@ -100,8 +100,9 @@ class Events(NamedTuple):
 
 @dataclass
 class Collision:
-    """sensors.py:206-211.  The dense rows keep the collision *flag*; the collidee id is not
-    tracked on the device, so it is reported as None."""
+    """sensors.py:206-211: one per vehicle the agent's chassis touched in the last physics update;
+    ``collidee_id`` is the actor id of that vehicle's owner (smarts.py:1284-1290).  The device reports the
+    collidees of an agent as a slot mask (``smx_outputs.collidees``)."""
 
     collidee_id: Optional[str]
 
@@ -263,8 +264,15 @@ class ObservationBuilder:
             angular_jerk=v3("ANG_JERK") if acc else None,
         )
         ev = rows["events"][slot]
+        # _process_collisions walks the set of collidee body ids; bodies are created in slot order, so the
+        # collisions come in slot order, each naming the owner of the vehicle hit (an agent id, or the
+        # scripted social vehicle's own name)
+        mask = int(rows["collidees"][slot]) & 0xFFFFFFFFFFFFFFFF if "collidees" in rows else 0
+        collisions = [Collision(collidee_id=self.agent_ids[j]) for j in range(len(self.agent_ids)) if (mask >> j) & 1]
+        if ev[nat.EV["COLLISIONS"]] and not collisions:  # rows from a caller that passed no collidee buffer
+            collisions = [Collision(collidee_id=None)]
         events = Events(
-            collisions=[Collision(collidee_id=None)] if ev[nat.EV["COLLISIONS"]] else [],
+            collisions=collisions,
             off_road=bool(ev[nat.EV["OFF_ROAD"]]), off_route=bool(ev[nat.EV["OFF_ROUTE"]]),
             on_shoulder=bool(ev[nat.EV["ON_SHOULDER"]]), wrong_way=bool(ev[nat.EV["WRONG_WAY"]]),
             not_moving=bool(ev[nat.EV["NOT_MOVING"]]), reached_goal=bool(ev[nat.EV["REACHED_GOAL"]]),

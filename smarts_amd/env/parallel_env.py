@@ -100,7 +100,6 @@ class ParallelEnv:
                 rewards = {aid: float(rows["reward"][e, i]) for i, aid in enumerate(core.agent_ids) if done_row[i]}
                 dones = {aid: True for i, aid in enumerate(core.agent_ids) if done_row[i]}
                 infos = {aid: {"score": None, "env_obs": None} for aid in dones}
-                core.step_count[e] = core.cfg.reset_elapsed_steps()
                 self._dones_registered[e] = 0
                 dones["__all__"] = True
             else:

@@ -43,6 +43,7 @@ def empty_dense(cfg, n):
         ego_pos=np.zeros((n, 3)), ego_f32=np.zeros((n, nat.EGO_F32_COUNT), np.float32),
         ego_lane=np.full((n, 2), -1, np.int16), events=np.zeros((n, nat.EV_COUNT), np.uint8),
         reward=np.zeros(n), dist=np.zeros(n), done=np.zeros(n, np.uint8), active=np.zeros(n, np.uint8),
+        collidees=np.zeros(n, np.uint64),
     )
     if cfg.waypoints:
         d.update(
@@ -100,6 +101,7 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
             len(ev["collisions"]) > 0, ev["off_road"], ev["off_route"], ev["on_shoulder"], ev["wrong_way"],
             ev["not_moving"], ev["reached_goal"], ev["reached_max_episode_steps"], ev["agents_alive_done"],
         ]
+        d["collidees"][i] = np.uint64(sum(1 << int(j) for j in ev["collisions"]))  # one bit per collidee slot
         d["dist"][i] = o["distance_travelled"]
         d["active"][i] = 1
         if rewards is not None:
@@ -147,7 +149,8 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
 
 
 INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
-            "nb_lane_id", "nb_slot", "nb_count", "ogm", "dagm", "lidar_hit", "via_near", "via_near_count", "via_hit"]
+            "nb_lane_id", "nb_slot", "nb_count", "ogm", "dagm", "lidar_hit", "via_near", "via_near_count", "via_hit",
+            "collidees"]
 
 
 def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
@@ -155,6 +158,8 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
     bad = []
     for k, a in ora.items():
         b = dev[k]
+        if k == "collidees":
+            b = np.ascontiguousarray(b).view(np.uint64)  # the device tensor is int64 (torch has no uint64 arithmetic)
         if k in INT_KEYS:
             if not np.array_equal(a, b):
                 idx = np.argwhere(a != b)[:4]
