@@ -70,7 +70,9 @@ struct KernelArgs {
 // Developer timing switches ("switch a piece off and see what the tick costs without it"): they exist
 // only in the -DSMX_DEBUG_TIMING variant of the library (smarts_amd/build.py --prof); in the shipped
 // library the test is the constant false and nothing, environment included, can drop work from a tick.
-#ifdef SMX_DEBUG_TIMING
+#if defined(SMX_ABLATE)  // developer variant without the stamps: the pieces named by a compile-time mask are off
+#define SMX_SKIP(args, bit) (((SMX_ABLATE) & (bit)) != 0)
+#elif defined(SMX_DEBUG_TIMING)
 #define SMX_SKIP(args, bit) (((args).debug_skip & (bit)) != 0)
 #else
 #define SMX_SKIP(args, bit) false
@@ -644,7 +646,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
 // tick.  The back-to-back form (large batches) is capped at 128 registers: four wavefronts per
 // SIMD; five (96 registers, 276 B of spills) was 1.5x slower at 131 k vehicles.
 #ifndef SMX_SCAN_WAVES
-#define SMX_SCAN_WAVES 4
+#define SMX_SCAN_WAVES 3
 #endif
 template <bool SPLIT>
 __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8))) __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
@@ -996,7 +998,8 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
 // cut at SMX_WPK_CAP — write their rows afterwards with the serial emitter, exactly as waypoints_for does;
 // their rows are skipped in step 3.
 // =================================================================================
-#define SMX_WPT_MAX_PATHS 8  // dense rows per vehicle (wp_paths) the table form handles
+#define SMX_WPT_MAX_PATHS 8  // dense rows per vehicle (wp_paths) the staged form handles
+#define SMX_WPT_PRELOAD 8    // knots of a path held in registers while it is interpolated
 #define SMX_WPT_VEHICLES (SMX_BLOCK / SMX_WP_LANES)
 enum { SMX_ROW_SKIP = -2, SMX_ROW_ZERO = -1 };
 
@@ -1233,19 +1236,52 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   // ---- 2 + 3, positions
   const smx_lp_rec r0 = (staged && listed) ? load_lp(m, a.knots.idx[path], 46) : smx_lp_rec{};
   auto fetch = [&](int k) { return a.knots.idx[(size_t)(k + 1) * paths + path]; };
+  // the knots of the path into registers, every load issued before anything waits for one (paths of more
+  // knots than SMX_WPT_PRELOAD interpolate straight from the list, a dependent load per knot)
+  constexpr int KP = SMX_WPT_PRELOAD;
+  const bool pre = staged && listed;
+  double kx[KP], ky[KP], kh[KP], kw[KP], ks_[KP];
+  int kl[KP];
+  double w0 = 0.0, s0 = 0.0;
+  {
+    int kid[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) kid[k] = (pre && k < nk) ? fetch(k) : 0;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const smx_lp_rec* r = m.lp_rec + kid[k];
+      const bool have = pre && k < nk;
+      kx[k] = have ? r->x : 0.0;
+      ky[k] = have ? r->y : 0.0;
+      kh[k] = have ? r->heading : 0.0;
+      kl[k] = have ? r->lane : 0;
+    }
+    if (pre) {
+      w0 = m.lane_width[r0.lane];
+      s0 = m.lane_speed[r0.lane];
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      // the tables are read only where the lane changes (few lanes of the wavefront ask at all)
+      const bool ask = pre && k < nk && kl[k] != (k == 0 ? (int)r0.lane : kl[k > 0 ? k - 1 : 0]);
+      kw[k] = ask ? m.lane_width[kl[k]] : 0.0;
+      ks_[k] = ask ? m.lane_speed[kl[k]] : 0.0;
+    }
+  }
   const int elems = SMX_WPT_VEHICLES * P * W;
   const size_t q0 = gid0 * (size_t)P * W;
   double gx = 0.0, gy = 0.0, gh = 0.0;  // first waypoint of this lane's path
   {
     double2* stage = reinterpret_cast<double2*>(stage_raw);
-    if (staged && listed)
-      interpolate_knots(m, r0, nk, n_first, D, px, py, my_row ? W : 1, fetch, [&](int i, const WaypointOut& w) {
-        if (i == 0) {
-          gx = w.x;
-          gy = w.y;
-        }
-        stage[i * SMX_BLOCK + col] = make_double2(w.x, w.y);
-      });
+    auto put_xy = [&](int i, const WaypointOut& w) {
+      if (i == 0) {
+        gx = w.x;
+        gy = w.y;
+      }
+      stage[i * SMX_BLOCK + col] = make_double2(w.x, w.y);
+    };
+    if (pre)
+      interpolate_knots_preloaded<KP>(m, r0, w0, s0, nk, n_first, D, px, py, my_row ? W : 1, kx, ky, kh, kl, kw, ks_, fetch, put_xy);
     __syncthreads();
     SMX_TSTAMP(tw2);
     SMX_TACC(1, tw1, tw2);
@@ -1278,7 +1314,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
     WpStageCell* stage = reinterpret_cast<WpStageCell*>(stage_raw);
     if (staged && listed) {
       int cached_lane = -1, cached_index = 0;  // consecutive waypoints mostly share their lane
-      interpolate_knots(m, r0, nk, n_first, D, px, py, my_row ? W : 1, fetch, [&](int i, const WaypointOut& w) {
+      auto put_rest = [&](int i, const WaypointOut& w) {
         if (i == 0) gh = w.heading;
         if (w.lane != cached_lane) {
           cached_lane = w.lane;
@@ -1292,7 +1328,8 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
         cell.lane_index = (signed char)cached_index;
         cell.pad = 0;
         stage[i * SMX_BLOCK + col] = cell;
-      });
+      };
+      interpolate_knots_preloaded<KP>(m, r0, w0, s0, nk, n_first, D, px, py, my_row ? W : 1, kx, ky, kh, kl, kw, ks_, fetch, put_rest);
     }
     __syncthreads();
     SMX_TSTAMP(tw3b);
@@ -1340,8 +1377,54 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   bool have_first_wp = false;
   double fwx = 0.0, fwy = 0.0, fwh = 0.0;
   if (live) {
-    if (serial_team) {
+    if (long_way) {
       waypoints_long_way<SMX_BLOCK>(a, m, seed, gid, p0, px, py, knots, have_first_wp, fwx, fwy, fwh);
+    } else if (serial_team) {
+      // ---- a lane branches inside the lookahead: paths are numbered lanes by index, branches depth-first,
+      // i.e. lane p's paths follow those of the lower lanes.  k_wp_walk counted them, so an exclusive prefix
+      // over the team gives every lane the numbers of its own paths, and each lane writes its own branches
+      // with the serial emitter (its own walks: the knot list only holds the first one).
+      int incl = cnt;
+      {
+        int t = __shfl_up(incl, 1, SMX_WP_LANES);
+        if (p0 >= 1) incl += t;
+        t = __shfl_up(incl, 2, SMX_WP_LANES);
+        if (p0 >= 2) incl += t;
+      }
+      const int n_paths_total = __shfl(incl, SMX_WP_LANES - 1, SMX_WP_LANES);
+      const int base = incl - cnt;
+      if (cnt > 0 && base < P) {
+        const int start = a.knots.idx[path];
+        BranchState bs;
+        bs.reset();
+        int idx = base;
+        do {
+          if (idx >= P) break;
+          WpRows rows = wp_rows(o, gid, P, W, idx);
+          const int n = equally_spaced_path(m, seed.f, bs, start, lookahead, px, py, knots, SMX_BLOCK, W,
+                                            [&](int i, const WaypointOut& w) {
+                                              if (i == 0 && idx == 0) {
+                                                gx = w.x;
+                                                gy = w.y;
+                                                gh = w.heading;
+                                              }
+                                              wp_put(m, rows, i, w);
+                                            });
+          wp_zero(rows, n < W ? n : W, W);
+          o.wp_count[gid * (P + 1) + 1 + idx] = (uint8_t)(n < W ? n : W);
+          ++idx;
+        } while (bs.advance());
+      }
+      for (int slot = n_paths_total + ((p0 - n_paths_total) & (SMX_WP_LANES - 1)); slot < P; slot += SMX_WP_LANES) {
+        wp_zero(wp_rows(o, gid, P, W, slot), 0, W);
+        o.wp_count[gid * (P + 1) + 1 + slot] = 0;
+      }
+      if (p0 == 0) o.wp_count[gid * (P + 1)] = (uint8_t)(n_paths_total > 255 ? 255 : n_paths_total);
+      const int src = started ? (__ffs(started) - 1) : 0;  // path 0 is the lowest started lane's first path
+      fwx = __shfl(gx, src, SMX_WP_LANES);
+      fwy = __shfl(gy, src, SMX_WP_LANES);
+      fwh = __shfl(gh, src, SMX_WP_LANES);
+      have_first_wp = n_paths_total > 0;
     } else {
       if (staged && !listed) {
         // more knots than the list holds: this path leaves through the serial emitter (its own walk)
@@ -2341,7 +2424,7 @@ struct smx_handle_s {
   // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
   // their own write stream — so they are enqueued on side streams between two events and overlap.
   hipStream_t side[2];
-  hipEvent_t ev_fork, ev_join[2];
+  hipEvent_t ev_fork, ev_fork_grid, ev_join[2];
   bool side_ready;
   const double* lidar_rays;
   smx_via* vias_dev;
@@ -2623,6 +2706,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
       SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    SMX_HIP(hipEventCreateWithFlags(&h->ev_fork_grid, hipEventDisableTiming));
     h->side_ready = true;
   }
   h->map_loaded = true;
@@ -2894,24 +2978,33 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const size_t sensor_lds = ogm_inline ? ogm_bytes : 0;
   // one pass of scan + sensors + commit (the tick's, then the reset pass restricted to new vehicles)
   auto observation_pass = [&](const KernelArgs& k, bool phases) {
+    // Large batches, no per-kernel timing asked: the grid maps and the lidar (which read poses only) leave on
+    // side stream 0 at once and overlap the scan — kernels bound by their own write stream beside one bound by
+    // arithmetic and load latency; observe goes to side stream 1 after the scan, the waypoint kernels stay on
+    // the caller's stream; all are joined before k_commit.
+    const bool fork = !small_batch && !phased && h->side_ready;
+    hipStream_t s_grid = stream, s_obs = stream;
+    if (fork) {
+      (void)hipEventRecord(h->ev_fork_grid, stream);
+      (void)hipStreamWaitEvent(h->side[0], h->ev_fork_grid, 0);
+      s_grid = h->side[0];
+      s_obs = h->side[1];
+      if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, s_grid, k);
+      if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
+      if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_grid, k);
+    }
     if (scan_split)
       hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     else
       hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
-    // large batches, no per-kernel timing asked: grid maps on side stream 0, observe (+ lidar) on side stream 1,
-    // waypoints on the caller's stream, joined before k_commit
-    const bool fork = !small_batch && !phased && h->side_ready;
-    hipStream_t s_grid = stream, s_obs = stream;
     if (fork) {
       (void)hipEventRecord(h->ev_fork, stream);
-      (void)hipStreamWaitEvent(h->side[0], h->ev_fork, 0);
       (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
-      s_grid = h->side[0];
-      s_obs = h->side[1];
+    } else {
+      if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
+      if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, k);
     }
-    if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, s_grid, k);
-    if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_OGM + 1], stream);
     if (small_batch) {
       hipLaunchKernelGGL(k_sensors, dim3(sensor_blocks), dim3(SMX_BLOCK), sensor_lds, stream, k);
@@ -2924,7 +3017,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       } else
         hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, k);
       hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
-      if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+      if (lidar_blocks && !fork) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, stream, k);
     }
     if (fork) {
       for (int i = 0; i < 2; ++i) {
@@ -3085,6 +3178,7 @@ extern "C" void smx_destroy(smx_handle h) {
       (void)hipEventDestroy(h->ev_join[i]);
     }
     (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_fork_grid);
   }
   if (h->vias_dev) (void)hipFree(h->vias_dev);
   if (h->via_off_dev) (void)hipFree(h->via_off_dev);

@@ -610,6 +610,115 @@ __device__ inline void interpolate_knots(const MapDev& m, const smx_lp_rec& r0, 
   }
 }
 
+// The same pass 2 for a path whose first KP knots are already in registers: x / y / heading / lane / lane
+// width / lane speed limit of knot k in element k of the arrays, that part of the knot loop unrolled so that
+// every element is a register.  A wavefront whose lanes each interpolate their own path meets a knot in one
+// lane or another at almost every step, and a record (or lane table) load at that point stalls all of them;
+// here those loads have been issued, together, before the loop starts.  Knots beyond KP (seldom needed: the
+// loop ends with the last waypoint kept) are fetched one by one as interpolate_knots does.  Same
+// expressions, same bits.
+template <int KP, class Fetch, class Emit>
+__device__ __forceinline__ void interpolate_knots_preloaded(const MapDev& m, const smx_lp_rec& r0, double w0, double s0,
+                                                            int nk, int n, double D, double px, double py, int max_emit,
+                                                            const double (&kx)[KP], const double (&ky)[KP],
+                                                            const double (&kh)[KP], const int (&kl)[KP],
+                                                            const double (&kw)[KP], const double (&ks)[KP],
+                                                            Fetch&& fetch, Emit&& emit) {
+  const int lane0 = r0.lane;
+  if (n == 1) {
+    if (max_emit > 0) {
+      WaypointOut o;
+      o.x = r0.x;
+      o.y = r0.y;
+      o.heading = r0.heading;
+      o.width = w0;
+      o.speed = s0;
+      o.lane = lane0;
+      emit(0, o);
+    }
+    return;
+  }
+  const int n_emit = min(n, max_emit);
+  if (n_emit <= 0) return;
+  const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+  const double k0x = r0.x + proj * r0.dirx, k0y = r0.y + proj * r0.diry;
+  const double step = D / (double)(n - 1);
+  int i = 0;
+  double t = 0.0;
+  double jx = k0x, jy = k0y, jh = r0.heading, jcum = 0.0;
+  int jlane = lane0;
+  int strict_lane = lane0;
+  Unwrap uw;
+  uw.start(jh);
+  double wj = w0, sj = s0;
+  // one knot: the waypoints of the interval it closes, then it becomes knot j
+  auto knot = [&](double qx, double qy, double qhead, int qlane, double wq, double sq) {
+    const double ex = qx - jx, ey = qy - jy;
+    const double qcum = jcum + sqrt(ex * ex + ey * ey);
+    const double qh = uw.push(qhead);
+    if (i < n_emit && t < qcum) {
+      const double den = qcum - jcum;
+      const double sx = (qx - jx) / den, sy = (qy - jy) / den, sh = (qh - jh) / den;
+      double sw = 0.0, ss = 0.0;
+      if (qlane != jlane) {
+        sw = (wq - wj) / den;
+        ss = (sq - sj) / den;
+      }
+      do {
+        WaypointOut o;
+        const double dt_ = t - jcum;
+        o.x = sx * dt_ + jx;
+        o.y = sy * dt_ + jy;
+        o.heading = sh * dt_ + jh;
+        o.width = sw * dt_ + wj;
+        o.speed = ss * dt_ + sj;
+        const int dl = (t == jcum) ? strict_lane : jlane;
+        o.heading = wrap_heading(o.heading);
+        o.lane = dl;
+        emit(i, o);
+        ++i;
+        t = (i == n - 1) ? D : (double)i * step;
+      } while (i < n_emit && t < qcum);
+    }
+    if (qcum > jcum) strict_lane = jlane;
+    jx = qx;
+    jy = qy;
+    jh = qh;
+    jcum = qcum;
+    jlane = qlane;
+    wj = wq;
+    sj = sq;
+  };
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    if (k < nk && i < n_emit) {
+      const bool change = kl[k] != jlane;
+      knot(kx[k], ky[k], kh[k], kl[k], change ? kw[k] : wj, change ? ks[k] : sj);
+    }
+  }
+  for (int k = KP; k < nk && i < n_emit; ++k) {
+    const smx_lp_rec cur = load_lp(m, fetch(k), 45);
+    double wq = wj, sq = sj;
+    if (cur.lane != jlane) {
+      wq = m.lane_width[SMX_BCHK(18, cur.lane, m.n_lanes)];
+      sq = m.lane_speed[cur.lane];
+    }
+    knot(cur.x, cur.y, cur.heading, cur.lane, wq, sq);
+  }
+  while (i < n_emit) {
+    WaypointOut o;
+    o.x = jx;
+    o.y = jy;
+    o.heading = wrap_heading(jh);
+    o.width = wj;
+    o.speed = sj;
+    o.lane = (t > jcum) ? jlane : strict_lane;
+    emit(i, o);
+    ++i;
+    t = (i == n - 1) ? D : (double)i * step;
+  }
+}
+
 template <class Emit>
 __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f, BranchState& bs, int start,
                                           int lookahead, double px, double py, int* knots, int kstride,
