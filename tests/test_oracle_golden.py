@@ -74,7 +74,7 @@ def test_waypoint_paths_match_reference(name, route_kind, lookahead, oracle_maps
     w = np.load(os.path.join(GOLDEN, f"waypoints_{name}_{route_kind}_{lookahead}.npz"))
     lane_ids = list(w["lane_ids"])
     route = [] if route_kind == "empty_route" else None
-    n_tie_sensitive = 0
+    tie_sensitive_poses = []
     for i, (px, py, ph) in enumerate(w["poses"]):
         pos = np.array([px, py, 0.0])
         # reference behaviour incl. scipy's order among exactly equidistant lanepoints: bit-exact
@@ -87,8 +87,11 @@ def test_waypoint_paths_match_reference(name, route_kind, lookahead, oracle_maps
         # the deterministic tie rule used for device parity may only differ on exact ties
         ok2, err2 = _paths_equal(om.waypoint_paths(pos, ph, lookahead, route=route), w, i, lane_ids)
         if not (ok2 and err2 == 0.0):
-            n_tie_sensitive += 1
-    assert n_tie_sensitive <= max(2, len(w["poses"]) // 50), n_tie_sensitive
+            tie_sensitive_poses.append(i)
+    # exactly the enumerated poses (tests/tie_sensitive.py): the GPU tests against these fixtures skip them by index
+    import tie_sensitive
+
+    assert tie_sensitive_poses == tie_sensitive.WAYPOINTS[(name, route_kind, lookahead)], tie_sensitive_poses
 
 
 @pytest.mark.parametrize("name", MAP_NAMES)
@@ -104,13 +107,21 @@ def test_nearest_lane_and_road_with_point(name, oracle_maps):
         assert (om.road_with_point((px, py, 0.0)) is not None) == bool(nr["on_road"][i])
 
 
+@pytest.mark.parametrize("tie_rule", ["kdtree", "index"])
 @pytest.mark.parametrize("name", MAP_NAMES)
-def test_lane_following_controller_matches_reference(name, oracle_maps):
+def test_lane_following_controller_matches_reference(name, tie_rule, oracle_maps):
+    """With the reference's KD-tree order among equidistant lanepoints every row is reproduced; with the
+    deterministic order the device uses, every row but the enumerated tie-sensitive ones."""
+    import tie_sensitive
+
     om = oracle_maps(name)
     g = np.load(os.path.join(GOLDEN, f"controller_{name}.npz"))
-    OLanePoints.tie_rule = "kdtree"
+    skip = tie_sensitive.CONTROLLER[name] if tie_rule == "index" else []
+    OLanePoints.tie_rule = tie_rule
     try:
         for i in range(len(g["x"])):
+            if i in skip:
+                continue
             veh = types.SimpleNamespace(
                 position=np.array([g["x"][i], g["y"][i], g["z"][i]]), heading=float(g["heading"][i]),
                 speed=float(g["speed"][i]), lateral_speed=float(g["lat_speed"][i]), yaw_rate_z=float(g["yaw_z"][i]),
