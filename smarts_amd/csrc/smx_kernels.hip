@@ -673,6 +673,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8
   }
 }
 
+// One half of the scan as a launch of its own (large batches): the road facts feed the observe role only and
+// the path seeds the waypoint kernels only, so the two go to different streams and each keeps the registers
+// it needs (the facts half alone fits more wavefronts per SIMD than the pair).
+template <int ROLE>
+__global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_half(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE)) return;
+  if (a.first_only && !(flags & SMX_F_FIRST)) return;
+  scan_role(a, a.map, c, gid, total, team_rank(), flags, ROLE);
+}
+
 // =================================================================================
 // waypoints role: waypoint paths (sensors.py:268-275, 972-985) + trip meter (sensors.py:880-947).
 // SMX_WP_LANES lanes per vehicle.  Team lane p takes seed lane p and writes its first path straight
@@ -2993,15 +3008,18 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
       if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_grid, k);
     }
-    if (scan_split)
-      hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
-    else
-      hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
-    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
     if (fork) {
-      (void)hipEventRecord(h->ev_fork, stream);
-      (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
+      // the scan's halves on two streams: path seeds (-> waypoint kernels) here, road facts (-> observe) on side 1
+      (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
+      hipLaunchKernelGGL(k_scan_half<0>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+      hipLaunchKernelGGL(k_scan_half<1>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    } else if (scan_split) {
+      hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     } else {
+      hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    }
+    if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
+    if (!fork) {
       if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
       if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, k);
     }
