@@ -2716,8 +2716,12 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     h->knots.cnt = (uint8_t*)(kb + off_cnt);
   }
   if (!h->side_ready) {
+    // lowest priority: the caller's stream carries the tick's critical chain (control -> seeds -> waypoints);
+    // the side kernels fill the chip around it instead of sharing it evenly
+    int prio_least = 0, prio_greatest = 0;
+    SMX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     for (int i = 0; i < 2; ++i) {
-      SMX_HIP(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+      SMX_HIP(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, prio_least));
       SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

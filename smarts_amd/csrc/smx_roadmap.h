@@ -363,7 +363,11 @@ struct KnotWalk {
   }
 
   __device__ __forceinline__ int first_of_run(const MapDev& m, int first) const {
+#ifdef SMX_WALK_CARRIED_NEXT0  // the round-1 form under investigation (tests/native/host_walk.cpp)
+    return first >= 0 ? first : cur.next0;
+#else
     return first >= 0 ? first : m.lp_rec[cur_idx].next0;
+#endif
   }
 
   // Advance to the next knot.  Returns its lanepoint index (its record is left in `rec`),

@@ -488,3 +488,41 @@ def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
                 shp["len"][v] = d
                 acc = acc + d
     return dict(lp_rec=rec, succ_rec=succ, lpg_pts=pts, sg_rec=seg, shape_rec=shp)
+
+
+_MAP_ARRAYS = [
+    ("lane_road", np.int32), ("lane_index", np.int32), ("lane_width", np.float64), ("lane_speed", np.float64),
+    ("lane_length", np.float64), ("lane_in_junction", np.uint8), ("lane_shape_off", np.int32),
+    ("shape_x", np.float64), ("shape_y", np.float64), ("lane_out_off", np.int32), ("lane_out_idx", np.int32),
+    ("road_lane_off", np.int32), ("road_lanes", np.int32), ("road_is_junction", np.uint8),
+    ("road_out_road", np.int32), ("lpg_off", np.int32), ("sg_off", np.int32),
+]
+
+
+def map_tables_struct(cm: "CompiledMap"):
+    """Fill ``smx_map_tables`` with pointers into (kept-alive) contiguous numpy arrays."""
+    from ._native import SmxMapTables
+
+    keep = []
+    t = SmxMapTables()
+    packed = cm.extras.get("packed") or pack_tables(cm)  # scenario_build.load_compiled_map attaches them
+    t.n_lanes, t.n_roads = cm.n_lanes, len(cm.road_ids)
+    t.n_lanepoints, t.n_shape_pts, t.n_succ = cm.n_lanepoints, len(cm.shape_x), len(packed["succ_rec"])
+    for name, dt in _MAP_ARRAYS:
+        arr = np.ascontiguousarray(getattr(cm, name), dtype=dt)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=dt)
+        keep.append(arr)
+        setattr(t, name, arr.ctypes.data)
+    for name in ("lp_rec", "succ_rec", "lpg_pts", "sg_rec", "shape_rec"):
+        arr = np.ascontiguousarray(packed[name])
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=arr.dtype)
+        keep.append(arr)
+        setattr(t, name, arr.ctypes.data)
+    t.lpg_x0, t.lpg_y0, t.lpg_cell = float(cm.lpg_origin[0]), float(cm.lpg_origin[1]), float(cm.lpg_cell)
+    t.lpg_nx, t.lpg_ny = int(cm.lpg_dims[0]), int(cm.lpg_dims[1])
+    t.sg_x0, t.sg_y0, t.sg_cell = float(cm.sg_origin[0]), float(cm.sg_origin[1]), float(cm.sg_cell)
+    t.sg_nx, t.sg_ny = int(cm.sg_dims[0]), int(cm.sg_dims[1])
+    t.default_lane_width = float(cm.default_lane_width)
+    return t, keep

@@ -1,0 +1,54 @@
+// The waypoint-path code of the device headers (smarts_amd/csrc/smx_roadmap.h: nearest10, pick_closest,
+// compute_path_seeds, KnotWalk, equally_spaced_path — the single-thread forms the kernels' team forms are
+// held to) compiled for the HOST, so that it can run under AddressSanitizer + UndefinedBehaviorSanitizer
+// against the reference-generated fixtures (tests/test_host_walk.py).  Why: round 1 met a stale `next0` read
+// from a by-value lanepoint record on one branch of KnotWalk::next ("in some builds"); the question was
+// undefined behaviour in this code versus device code generation.  -DSMX_WALK_CARRIED_NEXT0 restores the form
+// that misbehaved on the device (first_of_run reading cur.next0).
+#include "smx_roadmap.h"
+
+extern "C" {
+
+// waypoint_paths(pose, lookahead, route = empty Route) at (px, py, heading): every path in the reference's
+// order; returns the number of paths.  Path p has n[p] waypoints at x/y/h/w/s/lane[p * stride ...].
+int host_waypoint_paths(const smx_map_tables* m, double px, double py, double heading, int lookahead, int max_paths,
+                        int stride, int* n, double* x, double* y, double* h, double* w, double* s, int* lane) {
+  const PathSeeds seed = compute_path_seeds(*m, px, py, heading, 5.0, true);
+  int knots[SMX_MAX_KNOTS];
+  int idx = 0;
+  if (seed.road < 0) return 0;
+  for (int li = 0; li < seed.n_lanes; ++li) {
+    const int st = seed_start(*m, seed, li, px, py);
+    if (st < 0) continue;
+    BranchState bs;
+    bs.reset();
+    do {
+      if (idx < max_paths) {
+        const int p = idx;
+        n[p] = equally_spaced_path(*m, seed.f, bs, st, lookahead, px, py, knots, 1, stride,
+                                   [&](int i, const WaypointOut& o) {
+                                     x[p * stride + i] = o.x;
+                                     y[p * stride + i] = o.y;
+                                     h[p * stride + i] = o.heading;
+                                     w[p * stride + i] = o.width;
+                                     s[p * stride + i] = o.speed;
+                                     lane[p * stride + i] = o.lane;
+                                   });
+      } else {
+        equally_spaced_path(*m, seed.f, bs, st, lookahead, px, py, knots, 1, 0, [](int, const WaypointOut&) {});
+      }
+      ++idx;
+    } while (bs.advance());
+  }
+  return idx;
+}
+
+// nearest lane within `radius` and road_with_point at (px, py) — road_facts_scan, the one-thread form
+int host_nearest_lane(const smx_map_tables* m, double px, double py, double radius, double* dist, int* on_road) {
+  const RoadFacts f = road_facts_scan(*m, px, py, radius, 0, nullptr, nullptr);
+  *dist = f.dist;
+  *on_road = f.on_road ? 1 : 0;
+  return f.lane;
+}
+
+}  // extern "C"
