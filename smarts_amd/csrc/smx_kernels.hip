@@ -496,6 +496,287 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
 }
 
 // =================================================================================
+// Large batches: the controller as two launches.  In k_control the control law and the 24 physics substeps
+// run on ONE lane of each vehicle's team of four (154 of its 223 us at 131 k vehicles, three quarters of the
+// lanes masked off).  Here k_control_paths keeps the team work — candidate paths, nearest path, the wanted
+// path written as 17 waypoints to a hand-off in device memory, laid out [waypoint][component][vehicle] —
+// and k_control_law runs law + physics with one lane per vehicle: a quarter of the wavefronts, every lane
+// busy.  Small batches keep the single launch (one wavefront's latency is what they wait for).
+// =================================================================================
+struct CtrlHandoff {
+  double* path;  // [SMX_CTRL_WPS][3][E*N]: x, y, heading of the wanted path's waypoints
+  int32_t* n;    // [E*N] waypoints held; 0 = no path found (the reference asserts; the last command is kept)
+};
+
+// Controllers.perform_action's decoding of the Lane / LaneWithContinuousSpeed action (controllers/__init__.py:113-144)
+template <int SPACE>
+__device__ __forceinline__ bool decode_lane_action(const KernelArgs& a, size_t gid, double& target_speed, int& lane_change,
+                                                   double& hg, double& lg) {
+  if (SPACE == SMX_ACTION_SPACE_LANE) {
+    const int action = a.actions[gid];
+    if (action < 0) return false;
+    target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
+    lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
+    hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
+    lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+    return true;
+  }
+  const float act0 = a.actions_f32[gid * 3 + 0], act1 = a.actions_f32[gid * 3 + 1];
+  if (act0 != act0) return false;  // NaN = no action
+  target_speed = (double)act0;
+  lane_change = (int)act1;
+  lateral_gains_for_speed(target_speed, hg, lg);
+  return true;
+}
+
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a, const CtrlHandoff ho) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  int* knots = knot_scratch + threadIdx.x;
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int p0 = threadIdx.x % SMX_WP_LANES;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
+  if (gid >= total) return;  // whole teams leave together
+  const int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL)) return;
+  double target_speed, hg, lg;
+  int lane_change;
+  if (!decode_lane_action<SPACE>(a, gid, target_speed, lane_change, hg, lg)) return;  // uniform within a team
+  const PathSeeds seed = load_seeds(a, gid, total);  // found by k_scan at this very pose
+  const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
+  // Paths are numbered in the reference's order: seed lanes by index, branches depth-first.  Team lane p
+  // walks seed lanes p, p + 4, ... and measures the first waypoint of every path it meets
+  // (find_current_lane, lane_following_controller.py:367-374); counts exchanged by shuffles turn
+  // (lane, branch) into the global number.
+  int n_paths = 0;
+  double my_d = SMX_INF;
+  int my_idx = 0x7fffffff;
+  int goff0 = 0, cnt0 = 0;
+  if (seed.road >= 0) {
+    for (int r4 = 0; r4 < seed.n_lanes; r4 += SMX_WP_LANES) {  // uniform within a team
+      const int li = r4 + p0;
+      int cnt = 0, bj = 0x7fffffff;
+      double bd = SMX_INF;
+      if (li < seed.n_lanes) {
+        const int start = seed_start(m, seed, li, px, py);
+        if (start >= 0) {
+          BranchState bs;
+          bs.reset();
+          do {
+            double fx = 0.0, fy = 0.0;
+            equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 1,
+                                [&](int, const WaypointOut& w) {
+                                  fx = w.x;
+                                  fy = w.y;
+                                });
+            const double ex = fx - px, ey = fy - py;
+            const double d = sqrt(ex * ex + ey * ey);
+            if (d < bd) {  // strict: the lowest-numbered path wins ties (np.argmin)
+              bd = d;
+              bj = cnt;
+            }
+            ++cnt;
+          } while (bs.advance());
+        }
+      }
+      int incl = cnt;
+      {
+        int t = __shfl_up(incl, 1, SMX_WP_LANES);
+        if (p0 >= 1) incl += t;
+        t = __shfl_up(incl, 2, SMX_WP_LANES);
+        if (p0 >= 2) incl += t;
+      }
+      const int round_total = __shfl(incl, SMX_WP_LANES - 1, SMX_WP_LANES);
+      const int g = n_paths + incl - cnt;
+      if (r4 == 0) {
+        goff0 = g;
+        cnt0 = cnt;
+      }
+      if (bj != 0x7fffffff && (bd < my_d || (bd == my_d && g + bj < my_idx))) {
+        my_d = bd;
+        my_idx = g + bj;
+      }
+      n_paths += round_total;
+    }
+  }
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) {
+    const double od = __shfl_xor(my_d, msk, SMX_WP_LANES);
+    const int oi = __shfl_xor(my_idx, msk, SMX_WP_LANES);
+    if (od < my_d || (od == my_d && oi < my_idx)) {
+      my_d = od;
+      my_idx = oi;
+    }
+  }
+  if (n_paths <= 0) {  // uniform within a team
+    if (p0 == 0) ho.n[gid] = 0;
+    return;
+  }
+  int want = my_idx + lane_change;
+  want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
+  // the lane whose first seed lane holds path `want` walks to it again and writes its waypoints; a path of a
+  // later seed lane (roads with more than four lanes) is found by lane 0 the long way
+  const bool own = cnt0 > 0 && want >= goff0 && want < goff0 + cnt0;
+  int owners = own ? (1 << p0) : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) owners |= __shfl_xor(owners, msk, SMX_WP_LANES);
+  const int act_lane = owners ? (__ffs(owners) - 1) : 0;
+  if (p0 != act_lane) return;
+  auto put = [&](int i, const WaypointOut& w) {
+    double* q = ho.path + (size_t)(i * 3) * total + gid;
+    q[0] = w.x;
+    q[total] = w.y;
+    q[2 * total] = w.heading;
+  };
+  int n = 0;
+  if (owners) {
+    const int start = seed_start(m, seed, p0, px, py);
+    BranchState bs;
+    bs.reset();
+    int j = 0;
+    do {
+      if (j == want - goff0) {
+        n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, SMX_CTRL_WPS, put);
+        break;
+      }
+      equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0, [&](int, const WaypointOut&) {});
+      ++j;
+    } while (bs.advance());
+  } else {
+    int idx = 0;
+    for (int li = 0; li < seed.n_lanes && n == 0; ++li) {
+      const int start = seed_start(m, seed, li, px, py);
+      if (start < 0) continue;
+      BranchState bs;
+      bs.reset();
+      do {
+        if (idx == want) {
+          n = equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, SMX_CTRL_WPS, put);
+          break;
+        }
+        equally_spaced_path(m, seed.f, bs, start, SMX_CTRL_WPS - 1, px, py, knots, SMX_BLOCK, 0, [&](int, const WaypointOut&) {});
+        ++idx;
+      } while (bs.advance());
+    }
+  }
+  ho.n[gid] = n < SMX_CTRL_WPS ? n : SMX_CTRL_WPS;
+}
+
+// Control law + vehicle dynamics, one lane per vehicle (see k_control_paths).  Every action space; the
+// lane-following ones read the wanted path from the hand-off.
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, const CtrlHandoff ho) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE)) return;
+  if (flags & SMX_F_SOCIAL) {  // scripted lane follower: no controller, no dynamics
+    int lane = (int)SF(SMX_S_MCL_X), crossed = (int)SF(SMX_S_SPD_INT);
+    double offset = SF(SMX_S_MCL_Y), speed, x, y, heading;
+    SF(SMX_S_PREV_X) = SF(SMX_S_X);
+    SF(SMX_S_PREV_Y) = SF(SMX_S_Y);
+    const double cmd = c.social_model == SMX_SOCIAL_IDM ? SF(SMX_S_THROTTLE) : -1.0;
+    social_step(m, (int)(gid % c.num_vehicles), c.social_speed_factor, c.dt, lane, offset, crossed, speed, cmd);
+    social_pose(m, lane, offset, x, y, heading);
+    SF(SMX_S_X) = x;
+    SF(SMX_S_Y) = y;
+    SF(SMX_S_HEADING) = heading;
+    SF(SMX_S_U) = speed;
+    SF(SMX_S_MCL_X) = (double)lane;
+    SF(SMX_S_MCL_Y) = offset;
+    SF(SMX_S_SPD_INT) = (double)crossed;
+    return;
+  }
+  VehState s = load_vehicle(a, gid, total);
+  CtrlState cs;
+  cs.lat_int = SF(SMX_S_LAT_INT);
+  cs.spd_int = SF(SMX_S_SPD_INT);
+  cs.steer = SF(SMX_S_STEER);
+  cs.throttle = SF(SMX_S_THROTTLE);
+  cs.spd_err = SF(SMX_S_SPD_ERR);
+  cs.mcl_x = SF(SMX_S_MCL_X);
+  cs.mcl_y = SF(SMX_S_MCL_Y);
+  cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
+  ControlOut co;
+  // no action this tick: wheel torques do not persist, the steer motor target does
+  co.throttle = 0.0;
+  co.brake = 0.0;
+  co.steering = cs.steer;
+  constexpr bool lane_following = SPACE == SMX_ACTION_SPACE_LANE || SPACE == SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED;
+  if (lane_following) {
+    double target_speed, hg, lg;
+    int lane_change;
+    if (decode_lane_action<SPACE>(a, gid, target_speed, lane_change, hg, lg)) {
+      const int n = ho.n[gid];
+      if (n > 0) {
+        CtrlPath path;
+        path.n = n;
+#pragma unroll
+        for (int k = 0; k < SMX_CTRL_WPS; ++k) {
+          const double* q = ho.path + (size_t)(k * 3) * total + gid;
+          const bool held = k < n;
+          path.x[k] = held ? q[0] : 0.0;
+          path.y[k] = held ? q[total] : 0.0;
+          path.h[k] = held ? q[2 * total] : 0.0;
+        }
+        co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
+      } else {
+        // reference asserts "no waypoints found"; keep the last command
+        co.throttle = cs.throttle;
+        co.brake = 0.0;
+        co.steering = cs.steer;
+      }
+    }
+  } else if (SPACE == SMX_ACTION_SPACE_TRAJECTORY) {
+    if (a.traj_n[gid] > 0) {
+      PackedTraj t;
+      t.p = a.traj + gid * (size_t)(4 * SMX_TRAJ_COLS);
+      t.n = a.traj_n[gid];
+      co = trajectory_tracking_pd(s, cs, c.dt, t);
+    }
+  } else {
+    const float act0 = a.actions_f32[gid * 3 + 0], act1 = a.actions_f32[gid * 3 + 1], act2 = a.actions_f32[gid * 3 + 2];
+    if (!(act0 != act0)) {  // NaN = no action
+      if (SPACE == SMX_ACTION_SPACE_CONTINUOUS) {
+        co.throttle = clip_ref((double)act0, 0.0, 1.0);
+        co.brake = clip_ref((double)act1, 0.0, 1.0);
+        co.steering = clip_ref((double)act2, -1.0, 1.0);
+      } else {
+        // ActuatorDynamicController.perform_action (actuator_dynamic_controller.py:47-80)
+        const double change = clip_ref((double)act2, -1.0, 1.0);
+        co.throttle = clip_ref((double)act0, 0.0, 1.0);
+        co.brake = clip_ref((double)act1, 0.0, 1.0);
+        co.steering = clip_ref((1.0 - 0.001) * cs.steer + change * c.dt, -1.0, 1.0);
+      }
+      cs.steer = co.steering;  // last_steering_angle / the persisting steer target
+    }
+  }
+  SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
+  SF(SMX_S_PREV_Y) = s.y;
+  vehicle_step(s, co, c.dt);
+  SF(SMX_S_X) = s.x;
+  SF(SMX_S_Y) = s.y;
+  SF(SMX_S_HEADING) = s.heading;
+  SF(SMX_S_U) = s.u;
+  SF(SMX_S_V) = s.v;
+  SF(SMX_S_R) = s.r;
+  SF(SMX_S_DELTA) = s.delta;
+  SF(SMX_S_LAT_INT) = cs.lat_int;
+  SF(SMX_S_SPD_INT) = cs.spd_int;
+  SF(SMX_S_STEER) = cs.steer;
+  SF(SMX_S_THROTTLE) = cs.throttle;
+  SF(SMX_S_SPD_ERR) = cs.spd_err;
+  SF(SMX_S_MCL_X) = cs.mcl_x;
+  SF(SMX_S_MCL_Y) = cs.mcl_y;
+  a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
+}
+
+// =================================================================================
 // k_social (SMX_SOCIAL_IDM only): car following of the scripted social vehicles, one thread per
 // vehicle, before k_control moves anything: every follower reads its env-mates' poses and speeds as
 // they stand at the start of the tick and leaves its speed for the tick in SMX_S_THROTTLE (unused by a
@@ -2435,6 +2716,8 @@ struct smx_handle_s {
   size_t map_bytes;
   void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
   KnotLists knots;
+  void* ctrl_blob;   // CtrlHandoff of the two-launch controller (k_control_paths -> k_control_law)
+  CtrlHandoff ctrl;
   // Large batches: the sensor kernels of a tick are independent of each other (they read the pose and write
   // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
   // their own write stream — so they are enqueued on side streams between two events and overlap.
@@ -2519,6 +2802,8 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->map_bytes = 0;
   h->knots_blob = nullptr;
   h->knots = KnotLists{nullptr, nullptr, nullptr, nullptr, nullptr};
+  h->ctrl_blob = nullptr;
+  h->ctrl = CtrlHandoff{nullptr, nullptr};
   h->side_ready = false;
   h->lidar_rays = nullptr;
   // lane_following_controller.py:426-430: place_poles gains clipped to [0.02, 0.04] / [3.4, 4.1];
@@ -2714,6 +2999,14 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     h->knots.n = (int16_t*)(kb + off_n);
     h->knots.nk = (int16_t*)(kb + off_nk);
     h->knots.cnt = (uint8_t*)(kb + off_cnt);
+  }
+  if (!h->ctrl_blob) {
+    const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+    const size_t path_bytes = (size_t)SMX_CTRL_WPS * 3 * tv * sizeof(double);
+    SMX_HIP(hipMalloc(&h->ctrl_blob, path_bytes + tv * sizeof(int32_t)));
+    SMX_HIP(hipMemset(h->ctrl_blob, 0, path_bytes + tv * sizeof(int32_t)));
+    h->ctrl.path = (double*)h->ctrl_blob;
+    h->ctrl.n = (int32_t*)((char*)h->ctrl_blob + path_bytes);
   }
   if (!h->side_ready) {
     // lowest priority: the caller's stream carries the tick's critical chain (control -> seeds -> waypoints);
@@ -3055,8 +3348,32 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const bool lds_path = h->launch_strategy == SMX_LAUNCH_AUTO ? total * SMX_WP_LANES <= (size_t)1024 * 64 : small_batch;
   if (is_step && c.num_social > 0 && c.social_model == SMX_SOCIAL_IDM)
     hipLaunchKernelGGL(k_social, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
-  if (is_step) {
+  const bool two_launch_control = is_step && !small_batch && h->ctrl_blob;
+  if (two_launch_control) {
+    // large batches: candidate paths by teams of four, then law + physics with one lane per vehicle
+    const CtrlHandoff ho = h->ctrl;
     switch (c.action_space) {
+      case SMX_ACTION_SPACE_LANE:
+        hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        break;
+      case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
+        hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        break;
+      case SMX_ACTION_SPACE_CONTINUOUS:
+        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_CONTINUOUS>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        break;
+      case SMX_ACTION_SPACE_ACTUATOR_DYNAMIC:
+        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_ACTUATOR_DYNAMIC>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        break;
+      default:
+        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_TRAJECTORY>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        break;
+    }
+  }
+  if (is_step) {
+    if (!two_launch_control) switch (c.action_space) {
       case SMX_ACTION_SPACE_LANE:
         if (lds_path)
           hipLaunchKernelGGL((k_control<SMX_ACTION_SPACE_LANE, true>), dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a);
@@ -3193,6 +3510,7 @@ extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
   if (h->knots_blob) (void)hipFree(h->knots_blob);
+  if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
   if (h->side_ready) {
     for (int i = 0; i < 2; ++i) {
       (void)hipStreamSynchronize(h->side[i]);
