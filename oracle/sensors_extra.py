@@ -36,12 +36,16 @@ def ogm(ego, vehicles, width, height, resolution):
     cols = (np.arange(width) + 0.5 - width / 2) * resolution   # x to the right of the vehicle
     rows = (height / 2 - (np.arange(height) + 0.5)) * resolution  # y ahead of the vehicle
     X, Y = np.meshgrid(cols, rows)
+    ce, se = math.cos(h), math.sin(h)
     for v in vehicles:
         d = np.array([v.x - ego.x, v.y - ego.y])
         ex, ey = float(d @ right), float(d @ fwd)
-        dh = v.heading - h
-        vf = (-math.sin(dh), math.cos(dh))
-        vr = (math.cos(dh), math.sin(dh))
+        # the vehicle's axes in the ego frame, from each vehicle's own cos / sin of its heading (one pair per
+        # vehicle and tick serves every observer; smx_kernels.hip k_ogm_env): forward = (-sin vh, cos vh) and
+        # right = (cos vh, sin vh) projected on the ego's right / forward axes
+        cm, sm = math.cos(v.heading), math.sin(v.heading)
+        vf = (cm * se - sm * ce, sm * se + cm * ce)
+        vr = (cm * ce + sm * se, sm * ce - cm * se)
         qx, qy = X - ex, Y - ey
         inside = (np.abs(qx * vf[0] + qy * vf[1]) <= 0.5 * v.length) & (np.abs(qx * vr[0] + qy * vr[1]) <= 0.5 * v.width)
         grid[inside] = 255

@@ -1786,6 +1786,8 @@ struct __align__(16) SharedPose {
   double lane_dist;
   int lane;
   int alive;
+  short nl, nlidx;  // lane and lane index an observer reports for this vehicle (-1: none within its length)
+  int pad;
 };
 
 __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid) {
@@ -1848,8 +1850,23 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
   }
 }
 
+// The rows of several elements per agent (ego block, events, neighbour rows) go through LDS: every lane fills
+// its own vehicle's cells, then the workgroup sweeps each output array in memory order — the rows of its
+// vehicles are adjacent — so a store instruction writes consecutive elements instead of one element of 64 rows.
+// (Scalars per agent — done, active, reward, counts — are consecutive across lanes as they are.)
+#define SMX_NB_STAGE 16  // neighbour rows per agent the staged form handles (nb_max; StdObs keeps 10)
+struct ObsStage {
+  float ego_f32[SMX_BLOCK][SMX_EGO_F32_COUNT];
+  short ego_lane[SMX_BLOCK][2];
+  unsigned char events[SMX_BLOCK][SMX_EV_COUNT + 1];
+  signed char nb_list[SMX_BLOCK][SMX_NB_STAGE];  // env-mate slot of every neighbour row kept
+  unsigned char nb_kept[SMX_BLOCK];
+  unsigned char mode[SMX_BLOCK];                 // 1: this vehicle's rows are written this pass
+};
+
 __device__ __forceinline__ void observe_role(const KernelArgs& a, const int block) {
   __shared__ SharedPose pose[SMX_BLOCK];
+  __shared__ ObsStage stage;
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
@@ -1892,6 +1909,12 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     p.lane = my_lane;
     p.lane_dist = my_lane_dist;
     p.alive = (valid && alive) ? 1 : 0;
+    // what an observer reports as this vehicle's lane: nearest_lane(nv.pose.point, radius=vehicle.length)
+    // (sensors.py:244-246; every vehicle on this path has the sedan's length)
+    const int nl = (my_lane >= 0 && my_lane_dist < SMX_CHASSIS_LENGTH) ? my_lane : -1;
+    p.nl = (short)nl;
+    p.nlidx = (short)(nl >= 0 ? m.lane_index[nl] : -1);
+    stage.mode[local] = 0;
   }
   __syncthreads();
   SMX_TSTAMP(to1);
@@ -1909,7 +1932,9 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     o.done[gid] = 0;
     new_flags = flags & ~SMX_F_FIRST;
   }
+  const bool nb_staged = c.nb_max <= SMX_NB_STAGE;
   if (mine) {
+    stage.mode[local] = 1;
     const double px = s.x, py = s.y;
     int steps = a.st.steps[gid];
     const int env_ticks = first ? a.st.env_ticks[env] : a.st.env_ticks[env] + 1;  // smarts.py:261-262
@@ -1951,10 +1976,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     // ---- ego lane (sensors.py:277-285): nearest lane within max(10, 2 * default lane width)
     const int ego_lane = (my_lane >= 0 && my_lane_dist < fmax(10.0, 2.0 * m.default_lane_width)) ? my_lane : -1;
     // ---- ego vehicle state (sensors.py:314-329; read-back of chassis.py:493-566)
-    o.ego_pos[gid * 3 + 0] = px;
-    o.ego_pos[gid * 3 + 1] = py;
-    o.ego_pos[gid * 3 + 2] = SMX_BASE_HEIGHT;
-    float* ef = o.ego_f32 + gid * SMX_EGO_F32_COUNT;
+    float* ef = stage.ego_f32[local];  // (ego_pos comes from the pose block)
     ef[SMX_EGO_HEADING] = (float)wrap_heading(s.heading);
     ef[SMX_EGO_SPEED] = (float)speed;
     ef[SMX_EGO_STEERING] = (float)(-s.delta);
@@ -1968,8 +1990,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     ef[SMX_EGO_BOX + 0] = (float)SMX_CHASSIS_LENGTH;
     ef[SMX_EGO_BOX + 1] = (float)SMX_CHASSIS_WIDTH;
     ef[SMX_EGO_BOX + 2] = (float)SMX_CHASSIS_HEIGHT;
-    o.ego_lane[gid * 2 + 0] = (int16_t)ego_lane;
-    o.ego_lane[gid * 2 + 1] = (int16_t)(ego_lane >= 0 ? m.lane_index[ego_lane] : -1);
+    stage.ego_lane[local][0] = (short)ego_lane;
+    stage.ego_lane[local][1] = (short)(ego_lane >= 0 ? m.lane_index[ego_lane] : -1);
 
     // ---- accelerometer (sensors.py:1053-1084): finite differences over a 3-deep history
     {
@@ -2018,7 +2040,9 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
           double d = sqrt(dx * dx + dy * dy + dz * dz);
           if (!(d <= c.nb_radius)) continue;
         }
-        if (cnt < c.nb_max) {
+        if (cnt < c.nb_max && nb_staged) {
+          stage.nb_list[local][cnt] = (signed char)j;
+        } else if (cnt < c.nb_max) {
           size_t w = gid * c.nb_max + cnt;
           o.nb_pos[w * 3 + 0] = q.x;
           o.nb_pos[w * 3 + 1] = q.y;
@@ -2036,7 +2060,8 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
         }
         ++cnt;
       }
-      for (int q0 = cnt; q0 < c.nb_max; ++q0) {
+      stage.nb_kept[local] = (unsigned char)(cnt < c.nb_max ? cnt : c.nb_max);
+      for (int q0 = cnt; q0 < c.nb_max && !nb_staged; ++q0) {
         size_t w = gid * c.nb_max + q0;
         o.nb_pos[w * 3] = o.nb_pos[w * 3 + 1] = o.nb_pos[w * 3 + 2] = 0.0;
         o.nb_box[w * 3] = o.nb_box[w * 3 + 1] = o.nb_box[w * 3 + 2] = 0.0f;
@@ -2143,7 +2168,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
         }
       }
     }
-    uint8_t* ev = o.events + gid * SMX_EV_COUNT;
+    unsigned char* ev = stage.events[local];
     ev[SMX_EV_COLLISIONS] = collided ? 1 : 0;
     ev[SMX_EV_OFF_ROAD] = is_off_road ? 1 : 0;
     ev[SMX_EV_OFF_ROUTE] = is_off_route ? 1 : 0;
@@ -2197,6 +2222,53 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     }
   }
   if (valid) a.st.facts_i32[(size_t)SMX_FI_FLAGS_NEXT * total + gid] = new_flags;
+  // ---- copy-out of the staged rows, every array in memory order over the workgroup's vehicles
+  __syncthreads();
+  {
+    const int nth = (int)blockDim.x;
+    const int wg_veh = epb * n_veh;                           // vehicles of this workgroup (<= 64), gids g0 ...
+    const size_t g0 = (size_t)block * epb * n_veh;
+    for (int e = local; e < wg_veh * 3; e += nth) {           // ego_pos
+      const int v = e / 3, q = e - v * 3;
+      if (!stage.mode[v]) continue;
+      o.ego_pos[g0 * 3 + e] = q == 0 ? pose[v].x : (q == 1 ? pose[v].y : SMX_BASE_HEIGHT);
+    }
+    for (int e = local; e < wg_veh * SMX_EGO_F32_COUNT; e += nth) {
+      const int v = e / SMX_EGO_F32_COUNT;
+      if (stage.mode[v]) o.ego_f32[g0 * SMX_EGO_F32_COUNT + e] = stage.ego_f32[v][e - v * SMX_EGO_F32_COUNT];
+    }
+    for (int e = local; e < wg_veh * 2; e += nth)
+      if (stage.mode[e >> 1]) o.ego_lane[g0 * 2 + e] = stage.ego_lane[e >> 1][e & 1];
+    for (int e = local; e < wg_veh * SMX_EV_COUNT; e += nth) {
+      const int v = e / SMX_EV_COUNT;
+      if (stage.mode[v]) o.events[g0 * SMX_EV_COUNT + e] = stage.events[v][e - v * SMX_EV_COUNT];
+    }
+    if ((c.sensors & SMX_SENSOR_NEIGHBORS) && nb_staged && !SMX_SKIP(a, 8)) {
+      const int K = c.nb_max;
+      for (int e = local; e < wg_veh * K * 3; e += nth) {     // nb_pos, nb_box
+        const int v = e / (K * 3), r = e - v * (K * 3), k = r / 3, q = r - k * 3;
+        if (!stage.mode[v]) continue;
+        const bool held = k < (int)stage.nb_kept[v];
+        const SharedPose& P = pose[(v / n_veh) * n_veh + (held ? (int)stage.nb_list[v][k] : 0)];
+        o.nb_pos[g0 * K * 3 + e] = held ? (q == 0 ? P.x : (q == 1 ? P.y : SMX_BASE_HEIGHT)) : 0.0;
+        o.nb_box[g0 * K * 3 + e] =
+            held ? (float)(q == 0 ? SMX_CHASSIS_LENGTH : (q == 1 ? SMX_CHASSIS_WIDTH : SMX_CHASSIS_HEIGHT)) : 0.0f;
+      }
+      for (int e = local; e < wg_veh * K; e += nth) {         // the scalar neighbour rows
+        const int v = e / K, k = e - v * K;
+        if (!stage.mode[v]) continue;
+        const bool held = k < (int)stage.nb_kept[v];
+        const int j = held ? (int)stage.nb_list[v][k] : 0;
+        const SharedPose& P = pose[(v / n_veh) * n_veh + j];
+        const size_t w = g0 * K + e;
+        o.nb_heading[w] = held ? (float)P.heading : 0.0f;
+        o.nb_speed[w] = held ? (float)P.speed : 0.0f;
+        o.nb_lane_id[w] = (int16_t)(held ? P.nl : -1);
+        o.nb_lane_index[w] = (int8_t)(held ? P.nlidx : 0);
+        o.nb_slot[w] = (int8_t)(held ? j : -1);
+      }
+    }
+  }
   SMX_TSTAMP(to3);
   SMX_TACC(6, to0, to3);
 }
@@ -2315,8 +2387,9 @@ __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
         const double vh = wrap_heading(a.st.f64[(size_t)SMX_S_HEADING * total + og]);
         const double dx = vx - ex0, dy = vy - ey0;
         const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
-        const double dh = vh - eh;
-        const double vfx = -sin(dh), vfy = cos(dh), vrx = cos(dh), vry = sin(dh);
+        // the mate's axes in the ego frame from each vehicle's own cos / sin (the rule k_ogm_env shares)
+        const double cm = cos(vh), sm = sin(vh);
+        const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
         const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
         // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
         int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
@@ -2358,6 +2431,106 @@ __device__ __forceinline__ void ogm_role(const KernelArgs& a, const int block) {
   __syncthreads();
   int4* dst = reinterpret_cast<int4*>(a.out.ogm + gid * (size_t)bytes);
   for (int k = threadIdx.x; k < bytes / 16; k += SMX_BLOCK) dst[k] = reinterpret_cast<const int4*>(tile)[k];
+}
+
+// k_ogm_env (large batches): the same tiles, one workgroup of four wavefronts per ENV.  The env's poses are
+// loaded once, with one cos / sin pair per vehicle (a workgroup per observer reloads all its mates and takes
+// a sine and a cosine per mate: n x n of each per env); every wavefront then builds the tiles of a quarter of
+// the observers, one after the other, in its own LDS tile.
+struct OgmPose {
+  double x, y, ch, sh;  // centre, cos / sin of the wrapped heading
+  int alive, observes;
+};
+#define SMX_OGM_WAVES 4
+__global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
+  extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][H * W]
+  __shared__ OgmPose pose[SMX_BLOCK];
+  __shared__ OgmMate mates[SMX_OGM_WAVES][SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const int n_veh = c.num_vehicles;
+  const size_t total = (size_t)c.num_envs * n_veh;
+  const int env = (int)blockIdx.x;
+  const int W = c.ogm_width, H = c.ogm_height, bytes = W * H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)threadIdx.x < n_veh) {
+    const size_t gid = (size_t)env * n_veh + threadIdx.x;
+    const int flags = a.st.flags[gid];
+    OgmPose p;
+    p.alive = (flags & SMX_F_ALIVE) ? 1 : 0;
+    p.observes = ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST))) ? 1 : 0;
+    p.x = SF(SMX_S_X);
+    p.y = SF(SMX_S_Y);
+    const double h = wrap_heading(SF(SMX_S_HEADING));
+    p.ch = cos(h);
+    p.sh = sin(h);
+    pose[threadIdx.x] = p;
+  }
+  __syncthreads();
+  unsigned char* tile = tiles + (size_t)wave * bytes;
+  const double res = c.ogm_resolution;
+  const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
+  const int rounds = (n_veh + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
+  for (int it = 0; it < rounds; ++it) {  // the same trip count in every wavefront: barriers inside are legal
+    const int obs = it * SMX_OGM_WAVES + wave;
+    const bool live = obs < n_veh && pose[obs < n_veh ? obs : 0].observes;
+    if (live)
+      for (int k = lane; k < bytes / 16; k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    unsigned long long todo = 0ull;
+    if (live) {
+      const OgmPose e = pose[obs];
+      const double rx = e.ch, ry = e.sh;    // ego right axis
+      const double fx = -e.sh, fy = e.ch;   // ego forward axis
+      bool in_view = false;
+      if (lane < n_veh && pose[lane].alive) {
+        const OgmPose v = pose[lane];
+        const double dx = v.x - e.x, dy = v.y - e.y;
+        const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
+        const double cm = v.ch, sm = v.sh;
+        const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
+        const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
+        // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
+        int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
+        int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) / res) + 1;
+        c0 = max(c0, 0);
+        r0 = max(r0, 0);
+        c1 = min(c1, W - 1);
+        r1 = min(r1, H - 1);
+        if (c0 <= c1 && r0 <= r1) {
+          in_view = true;
+          OgmMate& q = mates[wave][lane];
+          q.cx = cx;
+          q.cy = cy;
+          q.vfx = vfx;
+          q.vfy = vfy;
+          q.vrx = vrx;
+          q.vry = vry;
+          q.c0 = c0;
+          q.r0 = r0;
+          q.bw = c1 - c0 + 1;
+          q.n_px = (c1 - c0 + 1) * (r1 - r0 + 1);
+        }
+      }
+      todo = __ballot(in_view);
+    }
+    __syncthreads();
+    while (todo != 0ull) {  // uniform in the wavefront
+      const OgmMate q = mates[wave][__ffsll((long long)todo) - 1];
+      todo &= todo - 1ull;
+      for (int p = lane; p < q.n_px; p += 64) {
+        const int r = q.r0 + p / q.bw, col = q.c0 + p % q.bw;
+        const double py = (0.5 * H - (r + 0.5)) * res - q.cy;
+        const double px = (col + 0.5 - 0.5 * W) * res - q.cx;
+        if (fabs(px * q.vfx + py * q.vfy) <= hl && fabs(px * q.vrx + py * q.vry) <= hw) tile[r * W + col] = 255;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      int4* dst = reinterpret_cast<int4*>(a.out.ogm + ((size_t)env * n_veh + obs) * (size_t)bytes);
+      for (int k = lane; k < bytes / 16; k += 64) dst[k] = reinterpret_cast<const int4*>(tile)[k];
+    }
+    __syncthreads();  // the tile and the mate list are reused
+  }
 }
 
 // =================================================================================
@@ -3289,6 +3462,14 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const unsigned sensor_blocks = (unsigned)(wp_blocks + obs_blocks + lidar_blocks + (ogm_inline ? (int)total : 0));
   const size_t sensor_lds = ogm_inline ? ogm_bytes : 0;
   // one pass of scan + sensors + commit (the tick's, then the reset pass restricted to new vehicles)
+  // OGM tiles on their own: per env (four wavefronts share the env's poses) on large batches while four
+  // tiles fit a workgroup's LDS, else per observer
+  auto launch_ogm = [&](hipStream_t st_, const KernelArgs& k) {
+    if (!small_batch && ogm_bytes * SMX_OGM_WAVES <= 64 * 1024)
+      hipLaunchKernelGGL(k_ogm_env, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES, st_, k);
+    else
+      hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, st_, k);
+  };
   auto observation_pass = [&](const KernelArgs& k, bool phases) {
     // Large batches, no per-kernel timing asked: the grid maps and the lidar (which read poses only) leave on
     // side stream 0 at once and overlap the scan — kernels bound by their own write stream beside one bound by
@@ -3301,7 +3482,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       (void)hipStreamWaitEvent(h->side[0], h->ev_fork_grid, 0);
       s_grid = h->side[0];
       s_obs = h->side[1];
-      if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, s_grid, k);
+      if (ogm_alone) launch_ogm(s_grid, k);
       if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
       if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_grid, k);
     }
@@ -3317,7 +3498,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     }
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
     if (!fork) {
-      if (ogm_alone) hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, stream, k);
+      if (ogm_alone) launch_ogm(stream, k);
       if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, stream, k);
     }
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_OGM + 1], stream);
