@@ -273,9 +273,11 @@ def main():
     # ranks taken per region; --repeats of them back to back, the median one is the reported value (§8d).
     # HIP events around the launch sequence of every TIMED_EVERY-th step (an event pair costs the stream ~6 us).
     region_s = []
+    alive_samples = []  # agents with a vehicle (rows being written), sampled outside the timed regions
     done_ticks = args.warmup
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
+        alive_samples.append(float(sim.out["active"].sum().item()))
         if world > 1:
             sharding.barrier()
         t0 = time.perf_counter()
@@ -296,6 +298,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         region_s.append(el)
+        alive_samples.append(float(sim.out["active"].sum().item()))
         done_ticks += args.steps
     elapsed = float(np.median(region_s))
     kernel_ms = sim.read_step_ms()
@@ -317,7 +320,11 @@ def main():
         kb = sim.kernel_bytes_per_agent_step()
         read_agent, write_agent = sum(r for r, _ in kb.values()), sum(w for _, w in kb.values())
         bytes_agent = read_agent + write_agent
-        agents = E * N
+        # Agents whose vehicle is gone write no rows and run no controller until their env restarts (the env
+        # restarts when ALL its agents are done, parallel_env.py:303-309): the algorithmic bytes of a tick are
+        # those of the agents alive in it.  Alive agents are sampled at both ends of every timed region.
+        alive_mean = float(np.mean(alive_samples))
+        agents = alive_mean
         avg_kernel_s = float(np.median(kernel_ms)) * 1e-3
         achieved = bytes_agent * agents / avg_kernel_s / 1e9
         workload_key = f"{args.config}:{scenario}:{E}x{N}"
@@ -367,6 +374,10 @@ def main():
                 "envs_per_gpu": E,
                 "vehicles_per_env": N,
                 "agent_steps_per_s": env_steps_per_s * N,
+                "alive_agents_per_tick": {"mean_rank0": alive_mean, "of": E * N,
+                                          "note": "an env restarts when all its agents are done; until then the "
+                                                  "agents already done have no vehicle: rows and byte counts "
+                                                  "are those of the alive agents"},
                 "sharding": f"{world} rank(s), envs [g*{total_envs}/{world}, (g+1)*{total_envs}/{world}) on GPU g "
                             f"({E} on rank 0); no data-path collective; per-tick reward/done all_gather (RCCL)",
                 "obs_build_ms_per_tick": obs_build_ms,

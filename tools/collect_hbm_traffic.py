@@ -55,10 +55,11 @@ def main():
     fetch, fd = read_counters(args.fetch, "FETCH_SIZE")
     write, wd = read_counters(args.write, "WRITE_SIZE")
     ours = [k for k in set(fetch) | set(write) if k.startswith("k_")]
-    steps_f = fd.get("k_control", 0)
-    steps_w = wd.get("k_control", 0)
+    # one k_commit dispatch per smx_step (the reset pass commits inside k_first)
+    steps_f = fd.get("k_commit", 0)
+    steps_w = wd.get("k_commit", 0)
     if not steps_f or not steps_w:
-        raise SystemExit("k_control not found in the counter files")
+        raise SystemExit("k_commit not found in the counter files")
     kernels = {}
     tot_r = tot_w = 0.0
     for k in sorted(ours):
