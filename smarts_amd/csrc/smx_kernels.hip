@@ -869,7 +869,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
     double lane_heading = 0.0;
     if (SMX_SKIP(a, 2048)) return;
     const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !SMX_SKIP(a, 64);  // uniform in the team
-    if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y);
+    if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y, h.dist);
     SMX_TSTAMP(ts2);
     SMX_TACC(11, ts1, ts2);
     if (rank == 0) {

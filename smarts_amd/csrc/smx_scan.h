@@ -436,11 +436,14 @@ __device__ __forceinline__ void position_at_offset(double x1, double y1, double 
 }
 
 // position_at_shape_offset (utils/math.py:319-331): the first segment v with cum[v] + len[v] > offset
+// `vfrom` (v0 <= vfrom): a vertex with cum[vfrom] <= offset.  No segment before it can be the answer
+// (cum[v + 1] = cum[v] + len[v] <= cum[vfrom] <= offset for v < vfrom), so the search starts there.
 __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, int v1, double offset, double& ox,
-                                                     double& oy) {
+                                                     double& oy, int vfrom) {
   const int r = team_rank();
   int hit = 0x7fffffff;
-  for (int v = v0 + r; v + 1 < v1; v += SMX_TEAM) {
+  (void)v0;
+  for (int v = vfrom + r; v + 1 < v1; v += SMX_TEAM) {
     const smx_shape_rec a = m.shape_rec[v];
     if (a.cum + a.len > offset) {
       hit = v;
@@ -459,7 +462,10 @@ __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, in
   position_at_offset(a.x, a.y, b.x, b.y, a.len, offset - a.cum, ox, oy);
 }
 
-__device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py) {
+// `dist_hint`: an upper bound of the point's distance to this lane's centre line known to the caller (the
+// nearest-lane sweep has just measured it), or SMX_INF: segments whose bounding box lies farther cannot hold
+// the minimum and are skipped from the first one on, not only once the sweep has found a good candidate.
+__device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py, double dist_hint) {
   const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
   const int r = team_rank();
   // ---- offset_along_lane: a vertex that equals the point wins (first such vertex) ...
@@ -477,7 +483,8 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
       // team's minimum nor tie it
       const double gx = fmax(fmax(fmin(a.x, b.x) - px, px - fmax(a.x, b.x)), 0.0);
       const double gy = fmax(fmax(fmin(a.y, b.y) - py, py - fmax(a.y, b.y)), 0.0);
-      const double keep = min_dist + 1e-6;
+      // (the hint comes from another evaluation of the same distance: 1e-6 covers their rounding many times over)
+      const double keep = fmin(min_dist, dist_hint) + 1e-6;
       if (gx * gx + gy * gy > keep * keep) continue;
     }
     const double d = a.len;
@@ -494,15 +501,18 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   }
 #pragma unroll
   for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) vertex_hit = min(vertex_hit, __shfl_xor(vertex_hit, msk, SMX_TEAM));
+  int v_near = v0;  // the vertex the offset was measured from
   double offset;
   if (vertex_hit != 0x7fffffff) {
     offset = m.shape_rec[vertex_hit].cum;
+    v_near = vertex_hit;
   } else {
     double bd = min_dist;
     int bv = min_v;
     team_min_pair(bd, bv);  // smallest distance, then the earliest segment
     const int owner = (bv == 0x7fffffff) ? 0 : ((bv - v0) & (SMX_TEAM - 1));
     offset = __shfl(min_offset, owner, SMX_TEAM);
+    if (bv != 0x7fffffff) v_near = bv;
   }
   // ---- vector_at_offset
   const double L = m.lane_length[lane];
@@ -516,8 +526,11 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   }
   s_off = fmax(s_off, 0.0);
   double p1x, p1y, p2x, p2y;
-  team_position_at_shape_offset(m, v0, v1, s_off, p1x, p1y);
-  team_position_at_shape_offset(m, v0, v1, e_off, p2x, p2y);
+  // both offsets lie at or beyond the vertex the offset was measured from, unless the end of the lane pulled
+  // them back (offset >= L): the lane's vertices before it need not be looked at again
+  const int vfrom = (m.shape_rec[v_near].cum <= s_off) ? v_near : v0;
+  team_position_at_shape_offset(m, v0, v1, s_off, p1x, p1y, vfrom);
+  team_position_at_shape_offset(m, v0, v1, e_off, p2x, p2y, vfrom);
   const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
   const double half = ang * 0.5;
   const double qz = sin(half), qw = cos(half);
