@@ -408,6 +408,8 @@ int smx_step_continuous(smx_handle h, const float* actions_dev, const smx_state*
 #define SMX_TRAJ_COLS 11
 int smx_step_trajectory(smx_handle h, const double* trajectories_dev, const int32_t* counts_dev, const smx_state* st,
                         const smx_spawns* sp, const smx_outputs* out, void* hip_stream);
+/* Waits for the stream, then reports what only the kernels could see: SMX_ERR_INVALID if a Lane action code
+ * outside -1..3 was met since the last smx_sync (such an agent is stepped as if it had sent no action). */
 int smx_sync(smx_handle h, void* hip_stream);
 /* Device-side timing: while enabled, every smx_step is bracketed by a hipEvent pair recorded on
  * the stream it is launched on (no synchronisation).  smx_read_step_ms waits for the recorded

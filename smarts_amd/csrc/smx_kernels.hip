@@ -63,7 +63,9 @@ struct KernelArgs {
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
   double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
   KnotLists knots;          // library-owned hand-off: k_wp_walk -> k_waypoints_tables
+  int32_t* status;          // library-owned device word of SMX_DEVICE_* bits, read and cleared by smx_sync
 };
+enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 was met (and treated as "no action")
 
 #define SF(field) a.st.f64[(size_t)(field) * total + gid]
 
@@ -271,6 +273,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 8))) __launch_bounds__(SMX
   bool has_action;
   if (space == SMX_ACTION_SPACE_LANE) {
     action = a.actions[gid];
+    if (action < SMX_ACTION_NONE || action > SMX_ACTION_CHANGE_LANE_RIGHT) {
+      // the reference looks the action string up in a dict and raises (controllers/__init__.py:137-144); a code
+      // that names no action is reported at the next smx_sync and moves nothing
+      if (p0 == 0) atomicOr(a.status, SMX_DEVICE_BAD_LANE_ACTION);
+      action = SMX_ACTION_NONE;
+    }
     has_action = action >= 0;
   } else if (space == SMX_ACTION_SPACE_TRAJECTORY) {
     has_action = a.traj_n[gid] > 0;
@@ -514,6 +522,10 @@ __device__ __forceinline__ bool decode_lane_action(const KernelArgs& a, size_t g
                                                    double& hg, double& lg) {
   if (SPACE == SMX_ACTION_SPACE_LANE) {
     const int action = a.actions[gid];
+    if (action < SMX_ACTION_NONE || action > SMX_ACTION_CHANGE_LANE_RIGHT) {
+      atomicOr(a.status, SMX_DEVICE_BAD_LANE_ACTION);  // reported at the next smx_sync; the code moves nothing
+      return false;
+    }
     if (action < 0) return false;
     target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
     lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
@@ -2891,6 +2903,7 @@ struct smx_handle_s {
   KnotLists knots;
   void* ctrl_blob;   // CtrlHandoff of the two-launch controller (k_control_paths -> k_control_law)
   CtrlHandoff ctrl;
+  int32_t* status_dev;  // SMX_DEVICE_* bits raised by the kernels
   // Large batches: the sensor kernels of a tick are independent of each other (they read the pose and write
   // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
   // their own write stream — so they are enqueued on side streams between two events and overlap.
@@ -2977,6 +2990,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->knots = KnotLists{nullptr, nullptr, nullptr, nullptr, nullptr};
   h->ctrl_blob = nullptr;
   h->ctrl = CtrlHandoff{nullptr, nullptr};
+  h->status_dev = nullptr;
   h->side_ready = false;
   h->lidar_rays = nullptr;
   // lane_following_controller.py:426-430: place_poles gains clipped to [0.02, 0.04] / [3.4, 4.1];
@@ -3172,6 +3186,10 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     h->knots.n = (int16_t*)(kb + off_n);
     h->knots.nk = (int16_t*)(kb + off_nk);
     h->knots.cnt = (uint8_t*)(kb + off_cnt);
+  }
+  if (!h->status_dev) {
+    SMX_HIP(hipMalloc((void**)&h->status_dev, sizeof(int32_t)));
+    SMX_HIP(hipMemset(h->status_dev, 0, sizeof(int32_t)));
   }
   if (!h->ctrl_blob) {
     const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
@@ -3407,6 +3425,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
   a.knots = h->knots;
+  a.status = h->status_dev;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
   // Small batches are bound by one wavefront's latency, so independent work is spread over more
@@ -3633,6 +3652,17 @@ extern "C" int smx_step_trajectory(smx_handle h, const double* trajectories_dev,
 extern "C" int smx_sync(smx_handle h, void* hip_stream) {
   if (!h) return SMX_ERR_INVALID;
   SMX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+  if (h->status_dev) {  // what the kernels could not report themselves
+    int32_t bits = 0;
+    SMX_HIP(hipMemcpy(&bits, h->status_dev, sizeof(bits), hipMemcpyDeviceToHost));
+    if (bits) {
+      SMX_HIP(hipMemset(h->status_dev, 0, sizeof(int32_t)));
+      if (bits & SMX_DEVICE_BAD_LANE_ACTION)
+        return fail(h, SMX_ERR_INVALID,
+                    "a Lane action code outside -1..3 reached smx_step since the last smx_sync; the agents that sent one "
+                    "were stepped as if they had sent no action");
+    }
+  }
   return SMX_OK;
 }
 
@@ -3692,6 +3722,7 @@ extern "C" void smx_destroy(smx_handle h) {
   if (h->map_blob) (void)hipFree(h->map_blob);
   if (h->knots_blob) (void)hipFree(h->knots_blob);
   if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
+  if (h->status_dev) (void)hipFree(h->status_dev);
   if (h->side_ready) {
     for (int i = 0; i < 2; ++i) {
       (void)hipStreamSynchronize(h->side[i]);

@@ -420,23 +420,26 @@ class BatchedSim:
     def step(self, actions: torch.Tensor) -> Dict[str, torch.Tensor]:
         if not self._was_reset:
             raise RuntimeError("step() before reset()")  # SMARTSNotSetupError (smarts.py:207-208)
+        if self.cfg.action_space == "Trajectory":
+            raise ValueError("ActionSpaceType.Trajectory steps through step_trajectory(trajectories, counts)")
+        lane = self.cfg.action_space == "Lane"
+        want_dtype, want_shape = (torch.int8, (self.E, self.N)) if lane else (torch.float32, (self.E, self.N, 3))
+        if actions.dtype != want_dtype or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=want_dtype).contiguous()
+        if tuple(actions.shape) != want_shape:
+            raise ValueError(f"{self.cfg.action_space} actions must have shape {want_shape}, got {tuple(actions.shape)}")
+        # only now that the call is known to go ahead does the learner block flip
         self._learner_k ^= 1
         self.out["learner"] = self._learner[self._learner_k]
         self._out.learner = self.out["learner"].data_ptr()  # same extent and dtype as the other block
-        if self.cfg.action_space == "Trajectory":
-            raise ValueError("ActionSpaceType.Trajectory steps through step_trajectory(trajectories, counts)")
-        if self.cfg.action_space == "Lane":
-            if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
-                actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
-            assert actions.shape == (self.E, self.N), actions.shape
+        if lane:
+            # (codes outside -1..3 cannot be seen from here without a device round trip: the kernel treats them
+            # as "no action" and smx_sync / BatchedSim.sync() reports them)
             rc = self.lib.smx_step(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
                                    C.byref(self._out), self._stream_ptr())
             nat.check(self.lib, self.handle, rc, "smx_step")
         else:
             # three floats per agent; NaN in the first one = no action this tick
-            if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
-                actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-            assert actions.shape == (self.E, self.N, 3), actions.shape
             rc = self.lib.smx_step_continuous(self.handle, actions.data_ptr(), C.byref(self._st), C.byref(self._sp),
                                               C.byref(self._out), self._stream_ptr())
             nat.check(self.lib, self.handle, rc, "smx_step_continuous")

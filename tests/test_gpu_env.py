@@ -296,3 +296,64 @@ def test_hiway_env_drivable_area_grid_map_and_std_obs():
     std = wrapped.reset()[AGENT_ID]
     assert std.dagm.shape == (64, 64, 1) and np.array_equal(std.dagm, grid.data)
     wrapped.close()
+
+
+def test_parallel_env_object_api_with_five_envs_and_auto_reset():
+    """The object API over more than two envs (round 1 sliced the [2, E, N] learner block by env and failed from
+    the third env on), across an auto-reset: every env hands back its own agents' observations, the
+    observation that follows an episode end is the first of the next episode and carries ITS clock
+    (step_count / elapsed_sim_time restart with the env, read from the device's env_ticks)."""
+    from smarts_amd.env import ParallelEnv
+
+    env = ParallelEnv(env_constructors=[_ctor(3)] * 5, auto_reset=True, seed=11)
+    acts = [{"Agent_0": "keep_lane", "Agent_1": "keep_lane"}] * 5
+    try:
+        first = env.reset()
+        assert len(first) == 5
+        pos0 = [tuple(o["Agent_0"].ego_vehicle_state.position) for o in first]
+        assert len(set(pos0)) == 5  # five different worlds (seed + i)
+        t0 = [o["Agent_0"].step_count for o in first]
+        assert len(set(t0)) == 1
+        obs, rew, dones, infos = env.step(acts)
+        assert all(set(o) == {"Agent_0", "Agent_1"} for o in obs) and all(d["__all__"] is False for d in dones)
+        assert [o["Agent_0"].step_count for o in obs] == [t0[0] + 1] * 5
+        obs, rew, dones, infos = env.step(acts)  # max_episode_steps = 3: every agent ends here, every env restarts
+        assert all(d["__all__"] is True for d in dones) and all(set(r) == {"Agent_0", "Agent_1"} for r in rew)
+        assert [o["Agent_0"].step_count for o in obs] == t0  # first observation of the NEXT episode, its own clock
+        assert [round(o["Agent_0"].elapsed_sim_time, 6) for o in obs] == [round(t0[0] * 0.1, 6)] * 5
+        obs, rew, dones, infos = env.step(acts)
+        assert all(d["__all__"] is False for d in dones)
+    finally:
+        env.close()
+
+
+def test_lane_action_code_that_names_no_action_is_reported_at_sync(compiled_maps):
+    """controllers/__init__.py:137-144 looks the Lane action up in a dict and raises on an unknown one.  The dense
+    path takes codes: one outside -1..3 moves nothing (the agent is stepped as if it had sent no action) and the
+    next smx_sync says so, once."""
+    import torch
+
+    from smarts_amd import _native as nat
+    from smarts_amd.engine import BatchedSim, SimConfig
+
+    for strategy in ("small", "large"):
+        sim = BatchedSim(compiled_maps("loop"), SimConfig(num_envs=2, num_vehicles=2, launch_strategy=strategy))
+        ref = BatchedSim(compiled_maps("loop"), SimConfig(num_envs=2, num_vehicles=2, launch_strategy=strategy))
+        sim.reset(), ref.reset()
+        bad = torch.tensor([[0, 7], [0, 0]], dtype=torch.int8, device="cuda")
+        none = torch.tensor([[0, -1], [0, 0]], dtype=torch.int8, device="cuda")
+        sim.step(bad), ref.step(none)
+        with pytest.raises(nat.SmxError, match="Lane action code"):
+            sim.sync()
+        sim.sync()  # reported once
+        ref.sync()
+        assert torch.equal(sim.state, ref.state)
+        sim.close(), ref.close()
+        # a wrong shape is refused before anything is enqueued (and before the learner block flips)
+        sim = BatchedSim(compiled_maps("loop"), SimConfig(num_envs=2, num_vehicles=2, launch_strategy=strategy))
+        sim.reset()
+        k = sim._learner_k
+        with pytest.raises(ValueError):
+            sim.step(torch.zeros((2, 3), dtype=torch.int8, device="cuda"))
+        assert sim._learner_k == k
+        sim.close()
