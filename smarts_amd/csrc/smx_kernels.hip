@@ -852,6 +852,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_social(const KernelArgs a) {
 //          (sumo_road_network.py:815-882), used by the waypoints role now and by k_control next tick
 // =================================================================================
 // one half of k_scan for one vehicle team (see k_scan)
+template <int TEAM>
 __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, const smx_config& c, size_t gid,
                                           size_t total, int rank, int flags, int role) {
   SMX_TSTAMP(ts0);
@@ -873,7 +874,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
     const bool social = (flags & SMX_F_SOCIAL) != 0;  // only its nearest lane is ever asked for (neighbour rows)
-    RoadFacts h = team_road_facts(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), social ? 0 : 4, cx, cy);
+    RoadFacts h = team_road_facts<TEAM>(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), social ? 0 : 4, cx, cy);
     SMX_TSTAMP(ts1);
     SMX_TACC(10, ts0, ts1);
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
@@ -881,7 +882,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
     double lane_heading = 0.0;
     if (SMX_SKIP(a, 2048)) return;
     const bool want_heading = !social && h.lane >= 0 && !m.lane_in_junction[h.lane] && !SMX_SKIP(a, 64);  // uniform in the team
-    if (want_heading) lane_heading = team_lane_heading_at_point(m, h.lane, s.x, s.y, h.dist);
+    if (want_heading) lane_heading = team_lane_heading_at_point<TEAM>(m, h.lane, s.x, s.y, h.dist);
     SMX_TSTAMP(ts2);
     SMX_TACC(11, ts1, ts2);
     if (rank == 0) {
@@ -897,7 +898,7 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   if (flags & SMX_F_SOCIAL) return;
   SMX_TSTAMP(ts3);
   Top10 t;
-  team_nearest10(m, s.x, s.y, t);
+  team_nearest10<TEAM>(m, s.x, s.y, t);
   SMX_TSTAMP(ts4);
   SMX_TACC(12, ts3, ts4);
   const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
@@ -908,17 +909,17 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
 #pragma unroll
     for (int k = 0; k < 10; ++k) sc.rel[k] = 0.0;
   } else {
-    sc = team_top10_heading_terms(m, t, s.heading);
+    sc = team_top10_heading_terms<TEAM>(m, t, s.heading);
   }
   SMX_TSTAMP(ts4b);
   SMX_TACC(9, ts4, ts4b);
-  const PathSeeds seed = team_compute_path_seeds(m, s.x, s.y, s.heading, 5.0, true, t, sc);
+  const PathSeeds seed = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, 5.0, true, t, sc);
   // without the waypoints sensor the observation still takes the first waypoint of
   // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
   // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
   int obs_start = -1, trip_start = -1;
   if (!wp_on || (flags & SMX_F_FIRST)) {
-    const PathSeeds ts = team_compute_path_seeds(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc);
+    const PathSeeds ts = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc);
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }
@@ -950,19 +951,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8
   // of one launch (even: road facts + lane heading, odd: lanepoint search + path seeds) and
   // overlap in time; on large ones every workgroup does both, one after the other
   const size_t gid = ((size_t)(SPLIT ? (blockIdx.x >> 1) : blockIdx.x) * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
-  const int rank = team_rank();
+  const int rank = team_rank<SMX_TEAM>();
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
   if (SPLIT) {
     if (blockIdx.x & 1)
-      scan_role(a, m, c, gid, total, rank, flags, 1);
+      scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 1);
     else
-      scan_role(a, m, c, gid, total, rank, flags, 0);
+      scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 0);
   } else {
-    scan_role(a, m, c, gid, total, rank, flags, 0);
-    scan_role(a, m, c, gid, total, rank, flags, 1);
+    scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 0);
+    scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 1);
   }
 }
 
@@ -973,12 +974,12 @@ template <int ROLE>
 __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_half(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM;
+  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM_LARGE;
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
-  scan_role(a, a.map, c, gid, total, team_rank(), flags, ROLE);
+  scan_role<SMX_TEAM_LARGE>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
 }
 
 // =================================================================================
@@ -2480,6 +2481,8 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
   __syncthreads();
   unsigned char* tile = tiles + (size_t)wave * bytes;
   const double res = c.ogm_resolution;
+  const double inv_res = 1.0 / res;  // for the pixel RECTANGLES only (an enumeration bound with a pixel of margin on
+                                     // every side); the pixel test itself keeps the oracle's arithmetic
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
   const int rounds = (n_veh + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
   for (int it = 0; it < rounds; ++it) {  // the same trip count in every wavefront: barriers inside are legal
@@ -2502,8 +2505,8 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
         const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
         const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
         // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
-        int c0 = (int)floor((cx - ext_x) / res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) / res + 0.5 * W - 0.5) + 1;
-        int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) / res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) / res) + 1;
+        int c0 = (int)floor((cx - ext_x) * inv_res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) * inv_res + 0.5 * W - 0.5) + 1;
+        int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) * inv_res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) * inv_res) + 1;
         c0 = max(c0, 0);
         r0 = max(r0, 0);
         c1 = min(c1, W - 1);
@@ -2520,7 +2523,7 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
           q.c0 = c0;
           q.r0 = r0;
           q.bw = c1 - c0 + 1;
-          q.n_px = (c1 - c0 + 1) * (r1 - r0 + 1);
+          q.n_px = r1 - r0 + 1;  // (here: the rectangle's height)
         }
       }
       todo = __ballot(in_view);
@@ -2529,11 +2532,18 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
     while (todo != 0ull) {  // uniform in the wavefront
       const OgmMate q = mates[wave][__ffsll((long long)todo) - 1];
       todo &= todo - 1ull;
-      for (int p = lane; p < q.n_px; p += 64) {
-        const int r = q.r0 + p / q.bw, col = q.c0 + p % q.bw;
-        const double py = (0.5 * H - (r + 0.5)) * res - q.cy;
-        const double px = (col + 0.5 - 0.5 * W) * res - q.cx;
-        if (fabs(px * q.vfx + py * q.vfy) <= hl && fabs(px * q.vrx + py * q.vry) <= hw) tile[r * W + col] = 255;
+      // the rectangle in 8 x 8 pixel blocks, lane = (row, column) inside a block: no division by its width
+      const int bh = q.n_px;
+      const int lr = lane >> 3, lc = lane & 7;
+      for (int rr = 0; rr < bh; rr += 8) {
+        for (int cc = 0; cc < q.bw; cc += 8) {
+          const int r = q.r0 + rr + lr, col = q.c0 + cc + lc;
+          if (rr + lr < bh && cc + lc < q.bw) {
+            const double py = (0.5 * H - (r + 0.5)) * res - q.cy;
+            const double px = (col + 0.5 - 0.5 * W) * res - q.cx;
+            if (fabs(px * q.vfx + py * q.vfy) <= hl && fabs(px * q.vrx + py * q.vry) <= hw) tile[r * W + col] = 255;
+          }
+        }
       }
     }
     __syncthreads();
@@ -2790,7 +2800,7 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
       if (pr < pairs) {
         const size_t gid = g0 + (pr >> 1);
         const int flags = a.st.flags[gid];
-        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role(a, m, c, gid, total, team_rank(), flags, (int)(pr & 1));
+        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role<SMX_TEAM>(a, m, c, gid, total, team_rank<SMX_TEAM>(), flags, (int)(pr & 1));
       }
     }
   }
@@ -3505,11 +3515,13 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       if (dagm_bytes) hipLaunchKernelGGL(k_dagm, dim3((unsigned)total), dim3(SMX_BLOCK), dagm_bytes, s_grid, k);
       if (lidar_blocks) hipLaunchKernelGGL(k_lidar, dim3((unsigned)lidar_blocks), dim3(SMX_BLOCK), 0, s_grid, k);
     }
-    if (fork) {
-      // the scan's halves on two streams: path seeds (-> waypoint kernels) here, road facts (-> observe) on side 1
-      (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
-      hipLaunchKernelGGL(k_scan_half<0>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
-      hipLaunchKernelGGL(k_scan_half<1>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+    if (!small_batch) {
+      // the scan's halves as two launches, on two streams when forked: path seeds (-> waypoint kernels) on the
+      // caller's, road facts (-> observe) on side 1
+      if (fork) (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
+      const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
+      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+      hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
     } else if (scan_split) {
       hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     } else {

@@ -8,17 +8,22 @@
 #include "smx_roadmap.h"
 
 #ifndef SMX_TEAM
-#define SMX_TEAM 8
+#define SMX_TEAM 8  // lanes per vehicle on small batches (one wavefront's latency); large batches: SMX_TEAM_LARGE
+#endif
+#ifndef SMX_TEAM_LARGE
+#define SMX_TEAM_LARGE 4  // fewer lanes repeat the per-vehicle uniform work (cell ranges, merges) at 131 k vehicles
 #endif
 
-__device__ __forceinline__ int team_rank() { return threadIdx.x & (SMX_TEAM - 1); }
+template <int TEAM>
+__device__ __forceinline__ int team_rank() { return threadIdx.x & (TEAM - 1); }
 
 // lexicographic (value, index) minimum across the team; every lane receives the result
+template <int TEAM>
 __device__ __forceinline__ void team_min_pair(double& d, int& idx) {
 #pragma unroll
-  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) {
-    double od = __shfl_xor(d, msk, SMX_TEAM);
-    int oi = __shfl_xor(idx, msk, SMX_TEAM);
+  for (int msk = TEAM / 2; msk >= 1; msk >>= 1) {
+    double od = __shfl_xor(d, msk, TEAM);
+    int oi = __shfl_xor(idx, msk, TEAM);
     if (od < d || (od == d && oi < idx)) {
       d = od;
       idx = oi;
@@ -26,15 +31,17 @@ __device__ __forceinline__ void team_min_pair(double& d, int& idx) {
   }
 }
 
+template <int TEAM>
 __device__ __forceinline__ int team_or(int v) {
 #pragma unroll
-  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) v |= __shfl_xor(v, msk, SMX_TEAM);
+  for (int msk = TEAM / 2; msk >= 1; msk >>= 1) v |= __shfl_xor(v, msk, TEAM);
   return v;
 }
 
 // ---------------------------------------------------------------------------------
 // road facts (see road_facts_scan): centre + 4 corners, one sweep, segments strided over the team
 // ---------------------------------------------------------------------------------
+template <int TEAM>
 __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double py, double radius, int n_corners,
                                             const double* cx, const double* cy) {
   RoadFacts out;
@@ -44,7 +51,7 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
   out.corner_mask = 0;
   int lane_key = 0x7fffffff;  // lane id as tie key (INT_MAX = none)
   int on_road = 0;
-  const int r = team_rank();
+  const int r = team_rank<TEAM>();
   const double road_radius = fmax(5.0, 2.0 * m.default_lane_width);  // sumo_road_network.py:705
   int cx0 = (int)floor((px - radius - m.sg_x0) / m.sg_cell);
   int cx1 = (int)floor((px + radius - m.sg_x0) / m.sg_cell);
@@ -58,7 +65,7 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
     for (int gy = cy0; gy <= cy1; ++gy) {
       const int row = gy * m.sg_nx;
       const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
-      for (int k = a + r; k < b; k += SMX_TEAM) {
+      for (int k = a + r; k < b; k += TEAM) {
         const smx_seg_rec s = m.sg_rec[k];
         {
           const double bx0 = fmin(s.x1, s.x2), bx1 = fmax(s.x1, s.x2), by0 = fmin(s.y1, s.y2), by1 = fmax(s.y1, s.y2);
@@ -110,17 +117,17 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
       }
     }
   }
-  team_min_pair(out.dist, lane_key);
+  team_min_pair<TEAM>(out.dist, lane_key);
   out.lane = lane_key == 0x7fffffff ? -1 : lane_key;
-  out.on_road = team_or(on_road) != 0;
-  out.corner_mask = team_or(out.corner_mask);
+  out.on_road = team_or<TEAM>(on_road) != 0;
+  out.corner_mask = team_or<TEAM>(out.corner_mask);
   return out;
 }
 
 // ---------------------------------------------------------------------------------
 // lanepoint grid, members strided over the team
 // ---------------------------------------------------------------------------------
-template <class F>
+template <int TEAM, class F>
 __device__ __forceinline__ void lp_ring_visit_team(const MapDev& m, int cx, int cy, int r, int rank, F&& f) {
   const int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
   for (int y = max(y0, 0); y <= min(y1, m.lpg_ny - 1); ++y) {
@@ -129,15 +136,15 @@ __device__ __forceinline__ void lp_ring_visit_team(const MapDev& m, int cx, int 
       const int xa = max(x0, 0), xb = min(x1, m.lpg_nx - 1);
       if (xa > xb) continue;
       const int a = m.lpg_off[row + xa], b = m.lpg_off[row + xb + 1];
-      for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+      for (int k = a + rank; k < b; k += TEAM) f(m.lpg_pts[k]);
     } else {
       if (x0 >= 0 && x0 < m.lpg_nx) {
         const int a = m.lpg_off[row + x0], b = m.lpg_off[row + x0 + 1];
-        for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+        for (int k = a + rank; k < b; k += TEAM) f(m.lpg_pts[k]);
       }
       if (x1 != x0 && x1 >= 0 && x1 < m.lpg_nx) {
         const int a = m.lpg_off[row + x1], b = m.lpg_off[row + x1 + 1];
-        for (int k = a + rank; k < b; k += SMX_TEAM) f(m.lpg_pts[k]);
+        for (int k = a + rank; k < b; k += TEAM) f(m.lpg_pts[k]);
       }
     }
   }
@@ -148,7 +155,7 @@ __device__ __forceinline__ void lp_ring_visit_team(const MapDev& m, int cx, int 
 // the same cells cost a dependent offset load per row segment (13 for R = 2) in front of their
 // members — with one wavefront per SIMD nothing hides that latency.  The order of the visit does
 // not matter to the callers (minima with an index tie-break).
-template <int R, class F>
+template <int TEAM, int R, class F>
 __device__ __forceinline__ void lp_block_visit_team(const MapDev& m, int cx, int cy, int rank, F&& f) {
   constexpr int ROWS = 2 * R + 1;
   int a[ROWS], b[ROWS];
@@ -170,7 +177,7 @@ __device__ __forceinline__ void lp_block_visit_team(const MapDev& m, int cx, int
     bool any = false;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-      const int k = a[i] + rank + j * SMX_TEAM;
+      const int k = a[i] + rank + j * TEAM;
       ok[i] = k < b[i];
       any = any || ok[i];
       rec[i] = m.lpg_pts[ok[i] ? k : 0];
@@ -184,6 +191,7 @@ __device__ __forceinline__ void lp_block_visit_team(const MapDev& m, int cx, int
 
 // The 10 nearest lanepoints (see nearest10).  Each lane keeps the best 10 of its share; the team
 // merges by repeatedly taking the smallest head.  Every lane ends with the same Top10.
+template <int TEAM>
 __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top10& res) {
   const int K = 10;
   double ld[K];
@@ -193,7 +201,7 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
     ld[i] = SMX_INF;
     li[i] = 0x7fffffff;
   }
-  const int rank = team_rank();
+  const int rank = team_rank<TEAM>();
   const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
   const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
   const int keff = min(K, m.n_lanepoints);
@@ -223,10 +231,10 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
   for (;;) {
     if (r == 0) {
       // rings 0-2 before the first merge: with 4 m cells the 10th neighbour is usually inside ring 2
-      lp_block_visit_team<2>(m, cx, cy, rank, take);
+      lp_block_visit_team<TEAM, 2>(m, cx, cy, rank, take);
       r = 3;
     } else {
-      lp_ring_visit_team(m, cx, cy, r, rank, take);
+      lp_ring_visit_team<TEAM>(m, cx, cy, r, rank, take);
       ++r;
     }
     // merge (on copies: the local lists keep growing if another ring is needed)
@@ -241,7 +249,7 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
     for (int j = 0; j < K; ++j) {
       double wd = hd[0];
       int wi = hi[0];
-      team_min_pair(wd, wi);
+      team_min_pair<TEAM>(wd, wi);
       res.d2[j] = wd;
       res.idx[j] = (wi == 0x7fffffff) ? -1 : wi;
       const bool mine = (hi[0] == wi) && (wi != 0x7fffffff);
@@ -266,11 +274,12 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
 }
 
 // Nearest lanepoint per key (lane or road), up to 4 keys at once (see closest_filtered4).
+template <int TEAM>
 __device__ inline void team_closest_filtered4(const MapDev& m, double px, double py, int k0, int k1, int k2, int k3,
                                               int nkeys, bool by_road, int* out_idx, double* out_d2) {
   double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
   int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-  const int rank = team_rank();
+  const int rank = team_rank<TEAM>();
   const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
   const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
   const int rmax = lp_max_ring(m, cx, cy);
@@ -293,16 +302,16 @@ __device__ inline void team_closest_filtered4(const MapDev& m, double px, double
   // them all), then ring by ring; a certified minimum is the global one whichever ring certifies it
   for (int r = 2; r <= max(rmax, 2); ++r) {
     if (r == 2)
-      lp_block_visit_team<2>(m, cx, cy, rank, take);
+      lp_block_visit_team<TEAM, 2>(m, cx, cy, rank, take);
     else
-      lp_ring_visit_team(m, cx, cy, r, rank, take);
+      lp_ring_visit_team<TEAM>(m, cx, cy, r, rank, take);
     bool all = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       rd[q] = bd[q];
       ri[q] = bi[q];
       if (q < nkeys) {
-        team_min_pair(rd[q], ri[q]);
+        team_min_pair<TEAM>(rd[q], ri[q]);
         all = all && ri[q] != 0x7fffffff && ring_covers(m, r, rd[q]);
       }
     }
@@ -312,21 +321,22 @@ __device__ inline void team_closest_filtered4(const MapDev& m, double px, double
   for (int q = 0; q < 4; ++q) {
     double d = bd[q];
     int i = bi[q];
-    if (q < nkeys) team_min_pair(d, i);
+    if (q < nkeys) team_min_pair<TEAM>(d, i);
     out_idx[q] = (q < nkeys && i != 0x7fffffff) ? i : -1;
     if (out_d2) out_d2[q] = d;
   }
 }
 
-// top10_heading_terms over the team: lane r evaluates candidates r, r + SMX_TEAM, ...; every lane
+// top10_heading_terms over the team: lane r evaluates candidates r, r + TEAM, ...; every lane
 // receives all ten by shuffles.
+template <int TEAM>
 __device__ inline Top10Scores team_top10_heading_terms(const MapDev& m, const Top10& t, double heading) {
-  const int rank = team_rank();
-  constexpr int PER = (10 + SMX_TEAM - 1) / SMX_TEAM;
+  const int rank = team_rank<TEAM>();
+  constexpr int PER = (10 + TEAM - 1) / TEAM;
   double mine[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int k = rank + j * SMX_TEAM;
+    const int k = rank + j * TEAM;
     int idx = 0;
 #pragma unroll
     for (int q = 0; q < 10; ++q)
@@ -336,11 +346,12 @@ __device__ inline Top10Scores team_top10_heading_terms(const MapDev& m, const To
   }
   Top10Scores sc;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) sc.rel[k] = __shfl(mine[k / SMX_TEAM], k % SMX_TEAM, SMX_TEAM);
+  for (int k = 0; k < 10; ++k) sc.rel[k] = __shfl(mine[k / TEAM], k % TEAM, TEAM);
   return sc;
 }
 
 // compute_path_seeds, team form (see smx_roadmap.h for the semantics)
+template <int TEAM>
 __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
                                                     double within_radius, bool has_route_object, const Top10& t,
                                                     const Top10Scores& sc) {
@@ -367,7 +378,7 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
         }
         int idx4[4];
         double d24[4];
-        team_closest_filtered4(m, px, py, s.f.road[0], s.f.road[1], -9, -9, s.f.n, true, idx4, d24);
+        team_closest_filtered4<TEAM>(m, px, py, s.f.road[0], s.f.road[1], -9, -9, s.f.n, true, idx4, d24);
         double bd = SMX_INF;
         int best = -1;
         for (int k = 0; k < s.f.n; ++k) {
@@ -396,7 +407,7 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
               k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
     SMX_TSTAMP(tp2);
     SMX_TACC(22, tp1, tp2);
-    team_closest_filtered4(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
+    team_closest_filtered4<TEAM>(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
     SMX_TSTAMP(tp3);
     SMX_TACC(23, tp2, tp3);
   }
@@ -438,12 +449,13 @@ __device__ __forceinline__ void position_at_offset(double x1, double y1, double 
 // position_at_shape_offset (utils/math.py:319-331): the first segment v with cum[v] + len[v] > offset
 // `vfrom` (v0 <= vfrom): a vertex with cum[vfrom] <= offset.  No segment before it can be the answer
 // (cum[v + 1] = cum[v] + len[v] <= cum[vfrom] <= offset for v < vfrom), so the search starts there.
+template <int TEAM>
 __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, int v1, double offset, double& ox,
                                                      double& oy, int vfrom) {
-  const int r = team_rank();
+  const int r = team_rank<TEAM>();
   int hit = 0x7fffffff;
   (void)v0;
-  for (int v = vfrom + r; v + 1 < v1; v += SMX_TEAM) {
+  for (int v = vfrom + r; v + 1 < v1; v += TEAM) {
     const smx_shape_rec a = m.shape_rec[v];
     if (a.cum + a.len > offset) {
       hit = v;
@@ -451,7 +463,7 @@ __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, in
     }
   }
 #pragma unroll
-  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) hit = min(hit, __shfl_xor(hit, msk, SMX_TEAM));
+  for (int msk = TEAM / 2; msk >= 1; msk >>= 1) hit = min(hit, __shfl_xor(hit, msk, TEAM));
   if (hit == 0x7fffffff) {
     const smx_shape_rec z = m.shape_rec[v1 - 1];
     ox = z.x;
@@ -465,15 +477,16 @@ __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, in
 // `dist_hint`: an upper bound of the point's distance to this lane's centre line known to the caller (the
 // nearest-lane sweep has just measured it), or SMX_INF: segments whose bounding box lies farther cannot hold
 // the minimum and are skipped from the first one on, not only once the sweep has found a good candidate.
+template <int TEAM>
 __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py, double dist_hint) {
   const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
-  const int r = team_rank();
+  const int r = team_rank<TEAM>();
   // ---- offset_along_lane: a vertex that equals the point wins (first such vertex) ...
   int vertex_hit = 0x7fffffff;
   // ... else the first segment at minimum distance
   double min_dist = SMX_INF, min_offset = -1.0;
   int min_v = 0x7fffffff;
-  for (int v = v0 + r; v < v1; v += SMX_TEAM) {
+  for (int v = v0 + r; v < v1; v += TEAM) {
     const smx_shape_rec a = m.shape_rec[v];
     if (a.x == px && a.y == py) vertex_hit = min(vertex_hit, v);
     if (v + 1 >= v1) continue;
@@ -500,7 +513,7 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
     }
   }
 #pragma unroll
-  for (int msk = SMX_TEAM / 2; msk >= 1; msk >>= 1) vertex_hit = min(vertex_hit, __shfl_xor(vertex_hit, msk, SMX_TEAM));
+  for (int msk = TEAM / 2; msk >= 1; msk >>= 1) vertex_hit = min(vertex_hit, __shfl_xor(vertex_hit, msk, TEAM));
   int v_near = v0;  // the vertex the offset was measured from
   double offset;
   if (vertex_hit != 0x7fffffff) {
@@ -509,9 +522,9 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   } else {
     double bd = min_dist;
     int bv = min_v;
-    team_min_pair(bd, bv);  // smallest distance, then the earliest segment
-    const int owner = (bv == 0x7fffffff) ? 0 : ((bv - v0) & (SMX_TEAM - 1));
-    offset = __shfl(min_offset, owner, SMX_TEAM);
+    team_min_pair<TEAM>(bd, bv);  // smallest distance, then the earliest segment
+    const int owner = (bv == 0x7fffffff) ? 0 : ((bv - v0) & (TEAM - 1));
+    offset = __shfl(min_offset, owner, TEAM);
     if (bv != 0x7fffffff) v_near = bv;
   }
   // ---- vector_at_offset
@@ -529,8 +542,8 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   // both offsets lie at or beyond the vertex the offset was measured from, unless the end of the lane pulled
   // them back (offset >= L): the lane's vertices before it need not be looked at again
   const int vfrom = (m.shape_rec[v_near].cum <= s_off) ? v_near : v0;
-  team_position_at_shape_offset(m, v0, v1, s_off, p1x, p1y, vfrom);
-  team_position_at_shape_offset(m, v0, v1, e_off, p2x, p2y, vfrom);
+  team_position_at_shape_offset<TEAM>(m, v0, v1, s_off, p1x, p1y, vfrom);
+  team_position_at_shape_offset<TEAM>(m, v0, v1, e_off, p2x, p2y, vfrom);
   const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
   const double half = ang * 0.5;
   const double qz = sin(half), qw = cos(half);
