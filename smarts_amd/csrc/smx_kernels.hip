@@ -40,6 +40,7 @@
 #define SMX_COLLISION_LEEWAY 0.05  // chassis.py:75-78
 #define SMX_WP_LANES 4             // lanes of a wavefront that share one vehicle (k_control, waypoints role)
 #define SMX_POSE_SCAN_RADIUS 10.0
+#define SMX_WPT_PRELOAD 8           // knots of a path held in registers while it is interpolated
 
 struct KernelArgs {
   smx_config cfg;
@@ -558,6 +559,123 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a,
   if (!decode_lane_action<SPACE>(a, gid, target_speed, lane_change, hg, lg)) return;  // uniform within a team
   const PathSeeds seed = load_seeds(a, gid, total);  // found by k_scan at this very pose
   const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
+  auto put = [&](int i, const WaypointOut& w) {
+    double* q = ho.path + (size_t)(i * 3) * total + gid;
+    q[0] = w.x;
+    q[total] = w.y;
+    q[2 * total] = w.heading;
+  };
+  // ---- no walk at all when the waypoints sensor's chain walks of the previous tick can be reused: they started
+  // from these very seeds (the controller asks its paths at the pose of the last observation), and a
+  // lookahead-16 path is the first 17 lanepoints of the lookahead-32 one: its knots are the longer path's
+  // knots less than 16 hops down plus the lanepoint 16 hops down (KnotLists.end16).  The first waypoint of
+  // every path of a seed lane is the projection of the vehicle on the start lanepoint's heading line
+  // (interpolate_knots at t = 0), so find_current_lane needs the start records only.  Taken when every seed
+  // lane of the team has a list for its start and filter and none branches inside the lookahead.
+  if (a.knots.key != nullptr && c.wp_lookahead >= SMX_CTRL_WPS - 1 && seed.road >= 0 && seed.n_lanes <= SMX_WP_LANES) {
+    const size_t paths = total * SMX_WP_LANES, path = gid * SMX_WP_LANES + p0;
+    const int start = p0 < seed.n_lanes ? seed_start(m, seed, p0, px, py) : -1;
+    bool reusable = true;
+    int n32 = 0;
+    if (start >= 0) {
+      reusable = a.knots.key[path] == start && a.knots.key[paths + path] == (seed.f.n > 0 ? seed.f.road[0] : -1) &&
+                 a.knots.key[2 * paths + path] == (seed.f.n > 1 ? seed.f.road[1] : -1) && a.knots.cnt[path] == 1;
+      n32 = a.knots.n[path];
+      reusable = reusable && n32 > 0;
+    }
+    int bad = reusable ? 0 : 1;
+#pragma unroll
+    for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) bad |= __shfl_xor(bad, msk, SMX_WP_LANES);
+    if (!bad) {  // uniform within a team
+      int started = start >= 0 ? (1 << p0) : 0;
+#pragma unroll
+      for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) started |= __shfl_xor(started, msk, SMX_WP_LANES);
+      const int n_paths = __popc(started);
+      if (n_paths == 0) {
+        if (p0 == 0) ho.n[gid] = 0;
+        return;
+      }
+      const int mine = __popc(started & ((1 << p0) - 1));  // this lane's path number
+      double my_d = SMX_INF;
+      int my_idx = 0x7fffffff;
+      smx_lp_rec r0 = smx_lp_rec{};
+      if (start >= 0) {
+        r0 = load_lp(m, start, 46);
+        const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+        const double fx = n32 == 1 ? r0.x : r0.x + proj * r0.dirx, fy = n32 == 1 ? r0.y : r0.y + proj * r0.diry;
+        const double ex = fx - px, ey = fy - py;
+        my_d = sqrt(ex * ex + ey * ey);
+        my_idx = mine;
+      }
+#pragma unroll
+      for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) {
+        const double od = __shfl_xor(my_d, msk, SMX_WP_LANES);
+        const int oi = __shfl_xor(my_idx, msk, SMX_WP_LANES);
+        if (od < my_d || (od == my_d && oi < my_idx)) {
+          my_d = od;
+          my_idx = oi;
+        }
+      }
+      int want = my_idx + lane_change;
+      want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
+      if (start < 0 || mine != want) return;
+      // ---- the wanted path's 17 waypoints from the list: knots into registers (every load in flight
+      // together), their arclength in path order (pass 1's additions), then the interpolation
+      const int n16 = n32 < SMX_CTRL_WPS ? n32 : SMX_CTRL_WPS;
+      const int nk16 = a.knots.nk16[path];
+      const int last = a.knots.end16[path];  // the last knot when it is not one of the list's
+      auto fetch = [&](int k) { return (k == nk16 - 1 && last >= 0) ? last : a.knots.idx[(size_t)(k + 1) * paths + path]; };
+      constexpr int KP = SMX_WPT_PRELOAD;
+      double kx[KP], ky[KP], kh[KP], kw[KP], ks_[KP];
+      int kl[KP];
+      {
+        int kid[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) kid[k] = k < nk16 ? fetch(k) : 0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const smx_lp_rec* r = m.lp_rec + kid[k];
+          const bool have = k < nk16;
+          kx[k] = have ? r->x : 0.0;
+          ky[k] = have ? r->y : 0.0;
+          kh[k] = have ? r->heading : 0.0;
+          kl[k] = have ? r->lane : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const bool ask = k < nk16 && kl[k] != (k == 0 ? (int)r0.lane : kl[k > 0 ? k - 1 : 0]);
+          kw[k] = ask ? m.lane_width[kl[k]] : 0.0;
+          ks_[k] = ask ? m.lane_speed[kl[k]] : 0.0;
+        }
+      }
+      double D = 0.0;
+      {
+        const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+        double lastx = r0.x + proj * r0.dirx, lasty = r0.y + proj * r0.diry;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          if (k < nk16) {
+            const double ex = kx[k] - lastx, ey = ky[k] - lasty;
+            D += sqrt(ex * ex + ey * ey);
+            lastx = kx[k];
+            lasty = ky[k];
+          }
+        }
+        for (int k = KP; k < nk16; ++k) {
+          const smx_lp_rec* r = m.lp_rec + fetch(k);
+          const double qx = r->x, qy = r->y;
+          const double ex = qx - lastx, ey = qy - lasty;
+          D += sqrt(ex * ex + ey * ey);
+          lastx = qx;
+          lasty = qy;
+        }
+      }
+      interpolate_knots_preloaded<KP>(m, r0, m.lane_width[r0.lane], m.lane_speed[r0.lane], nk16, n16, D, px, py, SMX_CTRL_WPS,
+                                      kx, ky, kh, kl, kw, ks_, fetch, put);
+      ho.n[gid] = n16;
+      return;
+    }
+  }
   // Paths are numbered in the reference's order: seed lanes by index, branches depth-first.  Team lane p
   // walks seed lanes p, p + 4, ... and measures the first waypoint of every path it meets
   // (find_current_lane, lane_following_controller.py:367-374); counts exchanged by shuffles turn
@@ -636,12 +754,6 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a,
   for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) owners |= __shfl_xor(owners, msk, SMX_WP_LANES);
   const int act_lane = owners ? (__ffs(owners) - 1) : 0;
   if (p0 != act_lane) return;
-  auto put = [&](int i, const WaypointOut& w) {
-    double* q = ho.path + (size_t)(i * 3) * total + gid;
-    q[0] = w.x;
-    q[total] = w.y;
-    q[2 * total] = w.heading;
-  };
   int n = 0;
   if (owners) {
     const int start = seed_start(m, seed, p0, px, py);
@@ -1308,7 +1420,6 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
 // their rows are skipped in step 3.
 // =================================================================================
 #define SMX_WPT_MAX_PATHS 8  // dense rows per vehicle (wp_paths) the staged form handles
-#define SMX_WPT_PRELOAD 8    // knots of a path held in registers while it is interpolated
 #define SMX_WPT_VEHICLES (SMX_BLOCK / SMX_WP_LANES)
 enum { SMX_ROW_SKIP = -2, SMX_ROW_ZERO = -1 };
 
@@ -1451,15 +1562,26 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
         a.knots.idx[path] = start;
         BranchState bs;
         bs.reset();
-        const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [&](int k, int idx) {
+        int below16 = 0;        // knots less than 16 hops down
+        bool knot_at_16 = false;
+        const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, SMX_CTRL_WPS - 1, [&](int k, int idx, int hop) {
           if (k <= SMX_WPK_CAP) a.knots.idx[(size_t)k * paths + path] = idx;
+          if (hop < SMX_CTRL_WPS - 1) ++below16;
+          if (hop == SMX_CTRL_WPS - 1) knot_at_16 = true;
         });
         n = w.n;
         nk = w.nk;
         D = w.D;
+        // the lookahead-16 path: the whole path when it is no longer than that, else the knots less than 16
+        // hops down and the lanepoint 16 hops down (a knot of the list, or the probed interpolated lanepoint)
+        a.knots.nk16[path] = (uint8_t)(w.n <= SMX_CTRL_WPS ? w.nk : below16 + 1);
+        a.knots.end16[path] = (w.n > SMX_CTRL_WPS && !knot_at_16) ? w.probe : -1;
+        a.knots.key[path] = start;
+        a.knots.key[paths + path] = seed.f.n > 0 ? seed.f.road[0] : -1;
+        a.knots.key[2 * paths + path] = seed.f.n > 1 ? seed.f.road[1] : -1;
         cnt = 1;
         while (bs.advance()) {
-          walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [](int, int) {});
+          walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, -1, [](int, int, int) {});
           if (cnt < 255) ++cnt;
         }
       }
@@ -1469,6 +1591,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
   a.knots.nk[path] = (int16_t)nk;
   a.knots.cnt[path] = (uint8_t)cnt;
   a.knots.D[path] = D;
+  if (n == 0) a.knots.key[path] = -1;  // nothing here for the next tick's controller to reuse
 }
 
 struct __align__(16) WpStageCell {  // second pass: everything of a waypoint but its position
@@ -2997,7 +3120,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->map_blob = nullptr;
   h->map_bytes = 0;
   h->knots_blob = nullptr;
-  h->knots = KnotLists{nullptr, nullptr, nullptr, nullptr, nullptr};
+  h->knots = KnotLists{};
   h->ctrl_blob = nullptr;
   h->ctrl = CtrlHandoff{nullptr, nullptr};
   h->status_dev = nullptr;
@@ -3187,15 +3310,21 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     const size_t paths = (size_t)h->cfg.num_envs * h->cfg.num_vehicles * SMX_WP_LANES;
     const size_t off_D = (size_t)(SMX_WPK_CAP + 1) * paths * sizeof(int32_t);
     const size_t off_n = off_D + paths * sizeof(double), off_nk = off_n + paths * sizeof(int16_t);
-    const size_t off_cnt = off_nk + paths * sizeof(int16_t), bytes = off_cnt + paths;
+    const size_t off_end = off_nk + paths * sizeof(int16_t), off_key = off_end + paths * sizeof(int32_t);
+    const size_t off_cnt = off_key + 3 * paths * sizeof(int32_t), off_nk16 = off_cnt + paths;
+    const size_t bytes = off_nk16 + paths;
     SMX_HIP(hipMalloc(&h->knots_blob, bytes));
     SMX_HIP(hipMemset(h->knots_blob, 0, bytes));
+    SMX_HIP(hipMemset((char*)h->knots_blob + off_key, 0xff, 3 * paths * sizeof(int32_t)));  // no list is valid yet
     char* kb = (char*)h->knots_blob;
     h->knots.idx = (int32_t*)kb;
     h->knots.D = (double*)(kb + off_D);
     h->knots.n = (int16_t*)(kb + off_n);
     h->knots.nk = (int16_t*)(kb + off_nk);
+    h->knots.end16 = (int32_t*)(kb + off_end);
+    h->knots.key = (int32_t*)(kb + off_key);
     h->knots.cnt = (uint8_t*)(kb + off_cnt);
+    h->knots.nk16 = (uint8_t*)(kb + off_nk16);
   }
   if (!h->status_dev) {
     SMX_HIP(hipMalloc((void**)&h->status_dev, sizeof(int32_t)));

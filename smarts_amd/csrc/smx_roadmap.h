@@ -352,6 +352,8 @@ struct KnotWalk {
   smx_lp_rec cur; // record of the lanepoint the walk stands on
   bool start;     // still on the start point (its own lane has not been checked by the filter)
   int cur_idx;    // index of `cur`
+  int probe_hop;  // -1, or a hop count: the lanepoint the path reaches after that many hops is noted in probe_idx
+  int probe_idx;  // (-1 while the path has not got that far) — where a path of that shorter lookahead would end
 
   __device__ __forceinline__ void begin(const MapDev& m, int start_lp, int lookahead) {
     remaining = lookahead;
@@ -360,6 +362,17 @@ struct KnotWalk {
     cur = load_lp(m, start_lp, 40);
     cur_idx = start_lp;
     start = true;
+    probe_hop = -1;
+    probe_idx = -1;
+  }
+
+  // the step from hop n - 1 covers `adv` hops along the run that starts at `first` (the knot itself when it is
+  // reached: at_knot): note the lanepoint at probe_hop if it lies on this stretch
+  __device__ __forceinline__ void probe(const MapDev& m, int first, int adv, int hops, int knot, bool at_knot, bool consecutive) {
+    if (probe_hop >= n && probe_hop <= n - 1 + adv) {
+      const int delta = probe_hop - (n - 1);
+      probe_idx = (at_knot && delta == hops) ? knot : chain_at(m, first_of_run(m, first), delta - 1, consecutive);
+    }
   }
 
   __device__ __forceinline__ int first_of_run(const MapDev& m, int first) const {
@@ -425,6 +438,7 @@ struct KnotWalk {
       // arriving on the knot is a hop onto its lane
       const bool ok = (hops > 1 || cur.n_next == 1 || first_lane == rec.lane) ? lane_allowed(m, f, rec.lane) : true;
       if (ok) {
+        probe(m, first, hops, hops, knot, true, consecutive);
         remaining -= hops;
         n += hops;
         cur = rec;
@@ -438,6 +452,7 @@ struct KnotWalk {
       if (hops == 1) return -1;
       // the knot's lane is closed: the path stops on the interpolated point before it
       const int fin = chain_at(m, first_of_run(m, first), hops - 2, consecutive);
+      probe(m, first, hops - 1, hops, knot, false, consecutive);
       rec = load_lp(m, fin, 42);
       n += hops - 1;
       remaining = 0;
@@ -459,6 +474,7 @@ struct KnotWalk {
       smx_dbg_aux[7] = ((const volatile smx_lp_rec*)m.lp_rec)[cur_idx].next0;
     }
 #endif
+    probe(m, first, remaining, hops, knot, false, consecutive);
     rec = load_lp(m, fin, 43);
     n += remaining;
     remaining = 0;
@@ -777,20 +793,28 @@ struct KnotLists {
   int16_t* n;     // [paths] lanepoints on the path; 0 = the seed lane starts no path
   int16_t* nk;    // [paths] knots after the start
   uint8_t* cnt;   // [paths] paths that start on this seed lane (1 unless the walk meets a branching)
+  // The controller's lookahead-16 path (lane_following_controller.py:96-98) runs along the same lanepoints: its
+  // knots are this list's knots less than 16 hops down plus the lanepoint 16 hops down.
+  uint8_t* nk16;  // [paths] knots of that path (the last one included)
+  int32_t* end16; // [paths] its last knot when that is not a knot of this list (an interpolated lanepoint), else -1
+  int32_t* key;   // [3][paths] what the list was walked for: start lanepoint, route filter roads (-1 none)
 };
 
 struct PathWalk {
-  int n;     // lanepoints on the path
-  int nk;    // knots after entry 0
-  double D;  // arclength over all knots
+  int n;      // lanepoints on the path
+  int nk;     // knots after entry 0
+  double D;   // arclength over all knots
+  int probe;  // the lanepoint `probe_hop` hops down the path, -1 if it is shorter
 };
 
-// Pass 1 of equally_spaced_path: sink(k, lanepoint index) is called for every knot k = 1..nk in path order.
+// Pass 1 of equally_spaced_path: sink(k, lanepoint index, hops from the start) is called for every knot
+// k = 1..nk in path order.
 template <class Sink>
 __device__ inline PathWalk walk_knots(const MapDev& m, const RouteFilter& f, BranchState& bs, int start, int lookahead,
-                                      double px, double py, Sink&& sink) {
+                                      double px, double py, int probe_hop, Sink&& sink) {
   KnotWalk w;
   w.begin(m, start, lookahead);
+  w.probe_hop = probe_hop;
   const smx_lp_rec r0 = w.cur;
   const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
   PathWalk out;
@@ -807,9 +831,10 @@ __device__ inline PathWalk walk_knots(const MapDev& m, const RouteFilter& f, Bra
     out.D += sqrt(ex * ex + ey * ey);
     lastx = rec.x;
     lasty = rec.y;
-    sink(out.nk, idx);
+    sink(out.nk, idx, w.n - 1);
   }
   out.n = w.n;
+  out.probe = w.probe_idx;
   return out;
 }
 
