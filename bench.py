@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--vehicles", type=int, default=None)
     ap.add_argument("--scenario", default=None)
     ap.add_argument("--phase-steps", type=int, default=100)
+    ap.add_argument("--launch-strategy", default="auto", choices=("auto", "small", "large"),
+                    help="how a tick is cut into launches (include/smx.h); auto = by vehicle count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help=argparse.SUPPRESS)
@@ -252,7 +254,7 @@ def main():
     cfg_kw["num_envs"] = E
     net = load_net(os.path.join(ROOT, "smarts_amd", "scenarios", scenario))
     cm = compile_map(net)
-    cfg = SimConfig(**cfg_kw)
+    cfg = SimConfig(launch_strategy=args.launch_strategy, **cfg_kw)
     spawns = make_spawns(cm, E, N, episodes=4, seed=42, first_env=plan.first_env)
     sim = BatchedSim(cm, cfg, device=device, spawns=spawns)
     actions = torch.from_numpy(action_stream(E, N, 42, plan.first_env)).to(device)

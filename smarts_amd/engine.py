@@ -390,7 +390,7 @@ class BatchedSim:
         ogm = (pose, o["ogm"]) if self.cfg.ogm else (0, 0)
         dagm = (pose, o["dagm"]) if self.cfg.dagm else (0, 0)
         ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
-                      and self.E * self.N <= 32768)  # smx_kernels.hip enqueue(): small batches only
+                      and self.small_form())  # smx_kernels.hip enqueue(): small batches only
         add = lambda a, b: (a[0] + b[0], a[1] + b[1])  # noqa: E731
         if (self.cfg.ogm and not ogm_inline) or self.cfg.dagm:
             kb["ogm"] = add((0, 0) if ogm_inline else ogm, dagm)  # their own launches (one timing phase)
@@ -399,6 +399,11 @@ class BatchedSim:
         if self.cfg.lidar is not None:
             kb["sensors"] = add(kb["sensors"], (pose, o["lidar_hit"] + o["lidar_point"]))
         return kb
+
+    def small_form(self) -> bool:
+        """Whether a tick runs in the SMALL launch form (smx_kernels.hip: SMX_LARGE_BATCH_VEHICLES)."""
+        s = self.cfg.launch_strategy
+        return s == "small" or (s == "auto" and self.E * self.N < nat.LARGE_BATCH_VEHICLES)
 
     def handoff_bytes_per_agent_step(self) -> int:
         """Bytes written by one kernel of the tick and read by a later one (path seeds, road facts, next flags):

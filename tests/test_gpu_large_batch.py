@@ -1,6 +1,6 @@
 """GPU parity of the LARGE launch strategy (smx_set_launch_strategy): one launch per role, k_scan's halves back
 to back, the register form of k_control, waypoint rows emitted in memory order from LDS knot tables
-(k_waypoints_tables), k_lidar / k_ogm on their own.  AUTO picks this form above 32768 vehicles, where an oracle
+(k_waypoints_tables), k_lidar / k_ogm on their own.  AUTO picks this form from 16384 vehicles on, where an oracle
 run is out of reach; forced onto oracle-sized batches here, every output is held to the oracle directly, and
 BASELINE-shaped batches above the threshold are held to small-strategy slices of themselves.
 """
@@ -104,15 +104,20 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
 
 
 @pytest.mark.parametrize("name,E,N,sub,ticks,extra", [
-    # BASELINE configs[3] shape: loop, 32-vehicle envs + OGM 64 x 64, above the 32768-vehicle threshold
+    # BASELINE configs[3] shape: loop, 32-vehicle envs + OGM 64 x 64, far above the 16384-vehicle threshold
     ("loop", 1056, 32, 4, 10, dict(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)),
     # BASELINE configs[4] shape: minicity, 64-vehicle envs + 100-ray lidar (k_lidar on its own, k_scan<false> on the big map)
     ("minicity", 520, 64, 2, 8, dict(lidar="planar100")),
     # BASELINE configs[2] shape: 4lane, 16-vehicle envs, collisions
     ("4lane", 2056, 16, 8, 10, {}),
+    # just above the threshold (16 640 vehicles), and between the LDS-path limit of k_control (8 192) and the
+    # threshold: the small form with the register form of k_control
+    ("loop", 520, 32, 4, 10, dict(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)),
+    ("4lane", 768, 16, 8, 10, {}),
 ])
 def test_batches_above_the_threshold_agree_with_small_slices(name, E, N, sub, ticks, extra, compiled_maps):
-    """AUTO above 32768 vehicles = the LARGE form.  The batch is `sub` distinct envs tiled E / sub times, so the
+    """AUTO from 16384 vehicles on = the LARGE form (below: the small form, past 8192 vehicles with the register
+    form of k_control).  The batch is `sub` distinct envs tiled E / sub times, so the
     first and the last slice must both equal a `sub`-env batch stepped in the small form."""
     import torch
 
@@ -122,7 +127,7 @@ def test_batches_above_the_threshold_agree_with_small_slices(name, E, N, sub, ti
     extra = dict(extra)
     if extra.get("lidar") == "planar100":
         extra["lidar"] = Planar100
-    assert E * N > 32768 and E % sub == 0
+    assert E * N > 8192 and E % sub == 0
     cm = compiled_maps(name)
     spawns = make_spawns(cm, sub, N, episodes=1, seed=9)
     big = np.tile(spawns, (1, E // sub, 1))
