@@ -95,6 +95,32 @@ class OLane:
         t = np.linalg.norm(offcenter_vector) * t_sign
         return s, t
 
+    def oncoming_lanes_at_offset(self, offset):
+        """sumo_road_network.py:371-395."""
+        result = []
+        radius = 1.1 * self.width_at_offset(offset)
+        pt = self.from_lane_coord(offset)
+        nearby_lanes = self._map.nearest_lanes(pt, radius=radius)
+        if not nearby_lanes:
+            return result
+        my_vect = self.vector_at_offset(offset)
+        my_norm = np.linalg.norm(my_vect)
+        if my_norm == 0:
+            return result
+        threshold = -0.995562  # cos(175*pi/180)
+        for lane, _ in nearby_lanes:
+            if lane is self:
+                continue
+            s, _t = lane.to_lane_coord(pt)
+            lv = lane.vector_at_offset(s)
+            lv_norm = np.linalg.norm(lv)
+            if lv_norm == 0:
+                continue
+            lane_angle = np.dot(my_vect, lv) / (my_norm * lv_norm)
+            if lane_angle < threshold:
+                result.append(lane)
+        return result
+
     def center_pose_heading_at_point(self, point):
         """Heading of ``center_pose_at_point`` (road_map.py:390-396)."""
         offset = self.offset_along_lane(point)
@@ -532,6 +558,60 @@ class ORoadNetwork:
             if dist < 0.5 * nl._width + 1e-1:
                 return nl.road
         return None
+
+    # ---- routes ----
+    def generate_routes(self, start_road, end_road, via=()):
+        """sumo_road_network.py:711-765 -> the route's road ids ([] = none found).  The edge search is
+        ``sumolib``'s ``getShortestPath`` (absent; restated in smarts_amd.sumo_map.SumoNet)."""
+        roads = [start_road] + list(via)
+        if end_road is not start_road:
+            roads.append(end_road)
+        edges = []
+        for cur_road, next_road in zip(roads, roads[1:] + [None]):
+            if not next_road:
+                edges.append(cur_road._se)
+                break
+            sub_route = self.net.getShortestPath(cur_road._se, next_road._se)[0] or []
+            if len(sub_route) < 2:
+                return []
+            edges.extend(sub_route[:-1])
+        if len(edges) == 1:
+            return [edges[0].getID()]
+        used_edges = []
+        edge_ids = []
+        for cur_edge, next_edge in zip(edges, edges[1:]):
+            for internal_route in self._internal_routes_between(cur_edge, next_edge):
+                used_edges.extend(internal_route)
+                edge_ids.extend([edge.getID() for edge in internal_route])
+        _, indices = np.unique(edge_ids, return_index=True)
+        return [used_edges[idx].getID() for idx in sorted(indices)]
+
+    def _internal_routes_between(self, start_edge, end_edge):
+        """sumo_road_network.py:767-800."""
+        routes = []
+        outgoing = start_edge.getOutgoing()
+        assert end_edge in outgoing
+        for connection in outgoing[end_edge]:
+            conn_route = [start_edge]
+            via_lane_id = connection.getViaLaneID()
+            while via_lane_id:
+                via_edge = self.lane_by_id(via_lane_id).road._se
+                conn_route.append(via_edge)
+                next_via_lane_ids = set(conn.getViaLaneID() for conn in via_edge.getOutgoing()[end_edge])
+                assert len(next_via_lane_ids) == 1
+                via_lane_id = list(next_via_lane_ids)[0]
+            conn_route.append(end_edge)
+            routes.append(conn_route)
+        return routes
+
+    def create_route(self, start_point, goal_point, route_vias=()):
+        """``Plan.create_route`` for a fixed-route mission (plan.py:316-349) -> road ids."""
+        start_lane = self.nearest_lane(start_point, include_junctions=False)
+        assert start_lane, "route must start in a lane"
+        end_lane = self.nearest_lane(goal_point, include_junctions=False)
+        assert end_lane, "route must end in a lane"
+        via_roads = [self.road_by_id(v) for v in route_vias]
+        return self.generate_routes(start_lane.road, end_lane.road, via_roads)
 
     # ---- waypoint paths ----
     def _waypoints_starting_at_lanepoint(self, lanepoint, lookahead, filter_road_ids, point):

@@ -244,9 +244,12 @@ class OracleEnv:
     """One SMARTS instance with N ego agents (and optional scripted social vehicles) on one map."""
 
     def __init__(self, road_map, spawns, configs, dt=0.1, social=(), social_speed_factor=0.8, vias=None,
-                 social_model="constant"):
+                 social_model="constant", missions=None):
         """``spawns``: (N, 4) array of x, y, heading, speed (vehicle centre) for the agents followed
-        by the social vehicles; ``social``: (lane id, arclength offset) per social vehicle."""
+        by the social vehicles; ``social``: (lane id, arclength offset) per social vehicle;
+        ``missions``: per agent ``None`` (endless mission, empty route: plan.py:321-323) or
+        ``dict(route=[road ids], goal=(x, y, radius))`` — a fixed-route mission with a
+        ``PositionalGoal`` (plan.py:86-120, 316-349; the route as ``ORoadNetwork.create_route`` plans it)."""
         self.road_map = road_map
         self.dt = dt
         self._round = rm.round_param_for_dt(dt)
@@ -262,8 +265,11 @@ class OracleEnv:
         self.agents = [_Agent(VehicleBody(*s), c, road_map, self) for s, c in zip(spawns[:n_agents], configs)]
         # per agent: the mission's vias as dicts(lane_id, position, hit_distance, required_speed, ...)
         self.vias = vias if vias is not None else [[] for _ in self.agents]
-        for ag in self.agents:
+        missions = missions if missions is not None else [None] * len(self.agents)
+        for ag, mission in zip(self.agents, missions):
             ag.consumed_vias = set()
+            ag.route = tuple(mission["route"]) if mission else ()
+            ag.goal = tuple(mission["goal"]) if mission else None
         self.social = [
             _Social(SocialBody(*spawns[n_agents + k], road_map.lane_by_id(lane_id), off, n_agents + k, social_speed_factor))
             for k, (lane_id, off) in enumerate(social)
@@ -337,7 +343,7 @@ class OracleEnv:
                         action = ctl.LANE_ACTION_NAMES[int(action)]
                     target_speed, lane_change = ctl.LANE_ACTIONS[action]
                 thr, brk, steer = ctl.perform_lane_following(
-                    rmap, ag.body, ag.ctrl, self.dt, target_speed=target_speed, lane_change=lane_change, route=()
+                    rmap, ag.body, ag.ctrl, self.dt, target_speed=target_speed, lane_change=lane_change, route=ag.route
                 )
             ag.body.control(throttle=thr, brake=brk, steering=steer)
         # physics (smarts.py:923-931)
@@ -404,7 +410,7 @@ class OracleEnv:
             o["neighbors"] = nvs
         # waypoints (sensors.py:268-275, 972-985)
         if cfg.waypoints_lookahead is not None:
-            waypoint_paths = rmap.waypoint_paths(b.position, b.heading, lookahead=cfg.waypoints_lookahead, route=())
+            waypoint_paths = rmap.waypoint_paths(b.position, b.heading, lookahead=cfg.waypoints_lookahead, route=ag.route)
         else:
             waypoint_paths = rmap.waypoint_paths(b.position, b.heading, lookahead=1, within_radius=b.length)
         closest_lane = rmap.nearest_lane(b.position)
@@ -465,13 +471,17 @@ class OracleEnv:
         return dict(linear_acceleration=la, angular_acceleration=aa, linear_jerk=lj, angular_jerk=aj)
 
     def _append_waypoint_if_new(self, ag, new_wp):
-        """sensors.py:900-938 (endless mission: every waypoint counts)."""
+        """sensors.py:900-938."""
         ag.last_dist_travelled = ag.dist_travelled
+        wp_road = self.road_map.lane_by_id(new_wp.lane_id).road.road_id
+        # an endless mission counts every waypoint, a fixed route only those on its roads (:908-913)
+        should_count_wp = ag.goal is None or wp_road in ag.route
         if not ag.wps_for_distance:
-            ag.wps_for_distance.append(new_wp)
+            if should_count_wp:
+                ag.wps_for_distance.append(new_wp)
             return
         recent = ag.wps_for_distance[-1]
-        if np.linalg.norm(new_wp.pos - recent.pos) > 0.5:
+        if np.linalg.norm(new_wp.pos - recent.pos) > 0.5 and should_count_wp:
             heading_vec = rm.radians_to_vec(recent.heading)
             disp_vec = new_wp.pos - recent.pos
             direction = np.sign(np.dot(heading_vec, disp_vec))
@@ -483,6 +493,9 @@ class OracleEnv:
         """sensors.py:443-489."""
         rmap, b, cfg = self.road_map, ag.body, ag.cfg
         reached_goal = False  # EndlessGoal (plan.py:76-84)
+        if ag.goal is not None:  # PositionalGoal.is_reached (plan.py:116-120) via Mission.is_complete (:220-222)
+            sqr_dist = (b.position[0] - ag.goal[0]) ** 2 + (b.position[1] - ag.goal[1]) ** 2
+            reached_goal = bool(sqr_dist <= ag.goal[2] ** 2)
         collided = len(ag.collisions) > 0
         is_off_road = not rmap.road_with_point(b.position)  # sensors.py:498-500
         is_on_shoulder = False  # sensors.py:502-509
@@ -492,7 +505,7 @@ class OracleEnv:
                 break
         is_not_moving = self._not_moving(ag)
         reached_max = cfg.max_episode_steps is not None and ag.steps >= cfg.max_episode_steps
-        is_off_route, is_wrong_way = self._off_route_and_wrong_way(b)
+        is_off_route, is_wrong_way = self._off_route_and_wrong_way(b, ag.route)
         agents_alive_done = self._agents_alive_done(cfg)
         done = (
             agents_alive_done
@@ -568,8 +581,8 @@ class OracleEnv:
         dist_array = (xs[:-1] - xs[1:]) ** 2 + (ys[:-1] - ys[1:]) ** 2
         return bool(np.sum(np.sqrt(dist_array)) < cfg.not_moving_distance)
 
-    def _off_route_and_wrong_way(self, b):
-        """sensors.py:527-594 with an empty route."""
+    def _off_route_and_wrong_way(self, b, route_roads=()):
+        """sensors.py:527-594."""
         radius = np.linalg.norm((b.length, b.width)) * 0.5 + 5
         nearest_lane = self.road_map.nearest_lane(b.position, radius=radius)
         if not nearest_lane:
@@ -579,4 +592,11 @@ class OracleEnv:
         else:
             target_heading = nearest_lane.center_pose_heading_at_point(tuple(b.position))
             is_wrong_way = bool(np.fabs(rm.heading_relative_to(b.heading, target_heading)) > 0.5 * np.pi)
-        return (False, is_wrong_way)  # no route roads => on route
+        if not route_roads or nearest_lane.road.road_id in route_roads or nearest_lane.in_junction:
+            return (False, is_wrong_way)
+        # not on the route, but perhaps just over the centre line in an oncoming lane (:566-571)
+        veh_offset = nearest_lane.offset_along_lane(tuple(b.position))
+        for on_lane in nearest_lane.oncoming_lanes_at_offset(veh_offset):
+            if on_lane.road.road_id in route_roads:
+                return (False, is_wrong_way)
+        return (True, is_wrong_way)

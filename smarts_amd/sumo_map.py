@@ -226,6 +226,41 @@ class SumoNet:
     def getLane(self, lane_id: str) -> Optional[Lane]:
         return self.id2lane.get(lane_id)
 
+    def getShortestPath(self, fromEdge: Edge, toEdge: Edge, maxCost: float = float("inf")):
+        """``sumolib.net.Net.getShortestPath`` (eclipse-sumo 1.10.0, absent here) for the arguments the
+        reference passes (``sumo_road_network.py:733-737``: two edges, defaults otherwise): Dijkstra over
+        the normal edges, an edge's cost = its length, the start edge's own length included; the heap
+        holds (cost, edge id, ...) so equal costs leave in edge-id order.  Returns (edges, cost) or
+        (None, inf).  Pinned by the reference's ``test_map.py:123-125`` (tests/test_missions.py)."""
+        import heapq
+
+        heap = [(fromEdge.getLength(), fromEdge.getID(), fromEdge, ())]
+        seen = set()
+        dist = {fromEdge: fromEdge.getLength()}
+        while heap:
+            cost, _, e1, path = heapq.heappop(heap)
+            if e1 in seen:
+                continue
+            seen.add(e1)
+            path = (e1, path)
+            if e1 is toEdge:
+                out = []
+                while path:
+                    out.append(path[0])
+                    path = path[1]
+                out.reverse()
+                return out, cost
+            if cost > maxCost:
+                return None, cost
+            for e2 in e1.getOutgoing():
+                if e2.isSpecial() or e2 in seen:
+                    continue
+                new_cost = cost + e2.getLength()
+                if e2 not in dist or new_cost < dist[e2]:
+                    dist[e2] = new_cost
+                    heapq.heappush(heap, (new_cost, e2.getID(), e2, path))
+        return None, float("inf")
+
     def all_lanes(self) -> List[Lane]:
         """Lanes in sumolib ``_allLanes`` order (edge file order, then lane index)."""
         out = []

@@ -674,6 +674,171 @@ def dump_via_sensor(net):
         track=np.array(track), near=np.array(near_out), hit=np.array(hit_out))
 
 
+def dump_missions(rn, net, rng, name):
+    """Fixed-route missions (plan.py:316-349): the reference's ``generate_routes`` (:711-765, over the
+    restated ``getShortestPath`` of smarts_amd.sumo_map), ``waypoint_paths(pose, lookahead, route)``
+    (:815-882), ``Sensors._vehicle_is_off_route_and_wrong_way`` (sensors.py:527-578) on mock
+    sim / vehicle objects, ``TripMeterSensor`` with a fixed route (:880-944) and
+    ``PositionalGoal.is_reached`` (plan.py:116-120)."""
+    from unittest.mock import Mock
+
+    from smarts.core.coordinates import Dimensions, Heading, Point, Pose
+    from smarts.core.plan import PositionalGoal
+    from smarts.core.sensors import Sensors, TripMeterSensor
+    from smarts.core.utils.math import fast_quaternion_from_angle
+
+    lane_ids = sorted(l.getID() for l in net.all_lanes())
+    lane_no = {lid: i for i, lid in enumerate(lane_ids)}
+    normal = [e for e in net.getEdges(False)]
+    # routes: random reachable (start, end) pairs, plus a single-road route
+    routes, pairs = [], []
+    tries = 0
+    want = {"loop": 3, "4lane": 8, "minicity": 8}[name]
+    while len(routes) < want and tries < 400:
+        tries += 1
+        a, b = (normal[i] for i in rng.integers(len(normal), size=2))
+        if len(routes) == 0:
+            b = a
+        r = rn.generate_routes(rn.road_by_id(a.getID()), rn.road_by_id(b.getID()))[0]
+        ids = [road.road_id for road in r.roads]
+        if not ids or (name == "minicity" and len(ids) > 60) or ids in [x[0] for x in routes]:
+            continue
+        routes.append((ids, r))
+        pairs.append((a.getID(), b.getID()))
+    out = dict(lane_ids=np.array(lane_ids), n_routes=np.array(len(routes)),
+               route_off=np.cumsum([0] + [len(ids) for ids, _ in routes]).astype(np.int32),
+               route_roads=np.array([rid for ids, _ in routes for rid in ids]),
+               route_pairs=np.array(pairs))
+
+    def make_pose(x, y, h):
+        return Pose(position=np.array([x, y, 0.0]), orientation=fast_quaternion_from_angle(Heading(h)), heading_=Heading(h))
+
+    class _LaneSet:
+        def __init__(self, lanes):
+            self._lanes = lanes
+
+        def all_lanes(self):
+            return self._lanes
+
+    all_lanes = net.all_lanes()
+    poses, pose_route = [], []
+    for k, (ids, r) in enumerate(routes):
+        on_route = [l for l in all_lanes if l.getEdge().getID() in ids]
+        # the oncoming twins of the route's roads ("-id" <-> "id", "...-NS" <-> "...-SN") and their neighbours
+        def twin(eid):
+            if eid.startswith("-"):
+                return eid[1:]
+            for a_, b_ in (("NS", "SN"), ("SN", "NS"), ("EW", "WE"), ("WE", "EW")):
+                if eid.endswith(a_):
+                    return eid[: -2] + b_
+            return "-" + eid
+        twins = {twin(e) for e in ids}
+        oncoming = [l for l in all_lanes if l.getEdge().getID() in twins]
+        n_on, n_tw, n_any = (40, 25, 15) if name != "minicity" else (30, 20, 10)
+        part = sample_poses(_LaneSet(on_route), rng, n_on, lateral=2.5, heading_noise=0.5, far_fraction=0.05)
+        if oncoming:
+            part += sample_poses(_LaneSet(oncoming), rng, n_tw, lateral=3.0, heading_noise=0.5, far_fraction=0.0)
+        part += sample_poses(net, rng, n_any)
+        poses += part
+        pose_route += [k] * len(part)
+    out["poses"] = np.array(poses)
+    out["pose_route"] = np.array(pose_route, dtype=np.int32)
+
+    # ---- waypoint paths along the route
+    for lookahead in (16, 32):
+        rec = dict(path_off=[0], wp_off=[0], x=[], y=[], heading=[], lane=[], lane_index=[], width=[], speed=[])
+        for (x, y, h), k in zip(poses, pose_route):
+            paths = rn.waypoint_paths(make_pose(x, y, h), lookahead=lookahead, route=routes[k][1])
+            for p_ in paths:
+                for wp in p_:
+                    rec["x"].append(float(wp.pos[0]))
+                    rec["y"].append(float(wp.pos[1]))
+                    rec["heading"].append(float(wp.heading))
+                    rec["lane"].append(lane_no[wp.lane_id])
+                    rec["lane_index"].append(int(wp.lane_index))
+                    rec["width"].append(float(wp.lane_width))
+                    rec["speed"].append(float(wp.speed_limit))
+                rec["wp_off"].append(len(rec["x"]))
+            rec["path_off"].append(len(rec["wp_off"]) - 1)
+        for key, v in rec.items():
+            out[f"wp{lookahead}_{key}"] = np.array(v)
+
+    # ---- off-route / wrong-way
+    off, wrong = [], []
+    for (x, y, h), k in zip(poses, pose_route):
+        pose = make_pose(x, y, h)
+        vehicle = Mock()
+        vehicle.id = "v"
+        vehicle.position = pose.position
+        vehicle.pose = pose
+        vehicle.chassis.dimensions = Dimensions(length=3.68, width=1.47, height=1.4)
+        sim = Mock()
+        sim.scenario.road_map = rn
+        sim.vehicle_index.sensor_state_for_vehicle_id.return_value.plan.route = routes[k][1]
+        o_, w_ = Sensors._vehicle_is_off_route_and_wrong_way(sim, vehicle)
+        off.append(bool(o_))
+        wrong.append(bool(w_))
+    out["off_route"] = np.array(off, dtype=np.uint8)
+    out["wrong_way"] = np.array(wrong, dtype=np.uint8)
+
+    # ---- trip meter with a fixed route: a drive along the route that leaves it sideways and returns
+    ids, r = routes[-1]
+    track = []
+    for rid in ids[:6]:
+        for lane in net.getEdge(rid).getLanes()[:1]:
+            shape = np.asarray(lane.getShape(False), dtype=np.float64)
+            total = float(np.sqrt(((shape[1:] - shape[:-1]) ** 2).sum(axis=1)).sum())
+            from smarts_amd.sumo_map import polyline_point_at
+            for s_ in np.arange(0.3, total, 1.9):
+                x, y = polyline_point_at(shape, float(s_))
+                x2, y2 = polyline_point_at(shape, min(float(s_) + 0.25, total))
+                h = math.atan2(y2 - y, x2 - x) - math.pi / 2 if (x2, y2) != (x, y) else 0.0
+                track.append((float(x), float(y), float(h)))
+    # three points of every twelve are replaced by points on lanes of roads that are not on the route
+    off_lanes = [l for l in all_lanes if l.getEdge().getID() not in ids]
+    strays = sample_poses(_LaneSet(off_lanes), rng, len(track), lateral=0.5, heading_noise=0.1, far_fraction=0.0)
+    track = [(strays[i] if (i % 12) >= 9 else p_) for i, p_ in enumerate(track)][:160]
+    vehicle = Mock()
+    vehicle.pose = make_pose(*track[0])
+    vehicle.length = 3.68
+    sim = Mock()
+    sim.road_map = rn
+    plan = Mock()
+    plan.mission.has_fixed_route = True
+    plan.route = r
+    meter = TripMeterSensor(vehicle, sim, plan)
+    dist, incr, counted = [], [], []
+    for (x, y, h) in track:
+        # the query of an agent without the waypoints sensor (sensors.py:271-275): not bound to the route
+        paths = rn.waypoint_paths(make_pose(x, y, h), lookahead=1, within_radius=3.68)
+        if paths:
+            meter.append_waypoint_if_new(paths[0][0])
+        dist.append(float(meter()))
+        incr.append(float(meter(increment=True)))
+        counted.append(len(meter._wps_for_distance))
+    out["trip_track"] = np.array(track)
+    out["trip_route"] = np.array(len(routes) - 1)
+    out["trip_dist"] = np.array(dist)
+    out["trip_incr"] = np.array(incr)
+    out["trip_counted"] = np.array(counted, dtype=np.int32)
+
+    # ---- PositionalGoal.is_reached
+    goal = PositionalGoal(position=Point(float(poses[0][0]), float(poses[0][1]), 0.0), radius=2.0)
+    probes = []
+    for ang in np.linspace(0, 2 * math.pi, 13):
+        for rad in (0.0, 1.9999, 2.0, 2.0001, 3.5):
+            probes.append((poses[0][0] + rad * math.cos(ang), poses[0][1] + rad * math.sin(ang)))
+    reached = []
+    for (x, y) in probes:
+        v = Mock()
+        v.position = np.array([x, y, 0.0])
+        reached.append(bool(goal.is_reached(v)))
+    out["goal"] = np.array([poses[0][0], poses[0][1], 2.0])
+    out["goal_probes"] = np.array(probes)
+    out["goal_reached"] = np.array(reached, dtype=np.uint8)
+    return out
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -697,7 +862,14 @@ def main():
     if os.environ.get("GOLDEN_ONLY", "") in ("", "vias"):
         np.savez_compressed(os.path.join(OUT, "via_sensor.npz"), **dump_via_sensor(load_net(os.path.join(REF, SCENARIOS["4lane"]))))
         print("via sensor goldens written")
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "missions"):
+        for name, rel in SCENARIOS.items():
+            net = load_net(os.path.join(REF, rel))
+            ms = dump_missions(make_reference_road_network(net), net, np.random.default_rng(4100 + len(name)), name)
+            np.savez_compressed(os.path.join(OUT, f"missions_{name}.npz"), **ms)
+            print(name, "missions: routes", int(ms["n_routes"]), "poses", len(ms["poses"]), "off-route",
+                  int(ms["off_route"].sum()), "wrong-way", int(ms["wrong_way"].sum()))
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias", "missions"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

@@ -19,5 +19,12 @@ WAYPOINTS = {
     ("minicity", "none", 32): [],
 }
 
+# missions_<map>.npz, waypoint paths along a route (wp<lookahead>_*): pose indices
+ROUTE_WAYPOINTS = {
+    ("loop", 16): [], ("loop", 32): [],
+    ("4lane", 16): [], ("4lane", 32): [],
+    ("minicity", 16): [], ("minicity", 32): [],
+}
+
 # controller_<map>.npz: row indices (the controller asks waypoint_paths with lookahead 16 at the vehicle pose)
 CONTROLLER = {"loop": [], "4lane": [179], "minicity": []}
