@@ -389,6 +389,21 @@ typedef struct smx_via {
   int32_t pad;
 } smx_via;
 int smx_set_vias(smx_handle h, const smx_via* vias_host, int32_t n, const int32_t* slot_off_host);
+/* Missions of the agent slots (plan.py:196-222, 316-349), shared by every env like the vias: n_slots = 0
+ * clears, else n_slots = cfg.num_vehicles.  route_len = 0: endless mission with an empty route (plan.py:321-323,
+ * what every slot has until this is called).  Otherwise a fixed route: roads[route_off .. route_off + route_len)
+ * are road table indices in route order (RoadMap.Route.roads as sumo_road_network.py:711-765 generates them:
+ * junction-internal roads included) and the goal is a PositionalGoal (plan.py:86-120).  With a fixed route
+ * the waypoint paths of the controller and the waypoints sensor follow the route (sumo_road_network.py:822-829,
+ * 862-882; lanepoints.py:666-683), off_route / reached_goal are live (sensors.py:491-496, 527-578) and the trip
+ * meter counts only waypoints on the route (sensors.py:908-913).  Host pointers; the library keeps a device
+ * copy.  Waits for the device; not to be called between smx_step and the use of its outputs. */
+typedef struct smx_mission {
+  double goal_x, goal_y, goal_radius;
+  int32_t route_off, route_len;
+} smx_mission;
+int smx_set_missions(smx_handle h, const smx_mission* missions_host, int32_t n_slots, const int32_t* route_roads_host,
+                     int32_t n_route_roads);
 /* Base ray directions (device, [lidar_rays][3]); reference lidar.py:89-113 */
 int smx_set_lidar_rays(smx_handle h, const double* rays_dev, int32_t n_rays);
 /* Re-initialise the envs whose mask byte is non-zero (NULL = all) from the spawn

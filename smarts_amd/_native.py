@@ -90,6 +90,10 @@ class SmxVia(C.Structure):
     _fields_ = [("x", _f64), ("y", _f64), ("hit_distance", _f64), ("required_speed", _f64), ("lane", _i32), ("pad", _i32)]
 
 
+class SmxMission(C.Structure):
+    _fields_ = [("goal_x", _f64), ("goal_y", _f64), ("goal_radius", _f64), ("route_off", _i32), ("route_len", _i32)]
+
+
 class SmxSpawns(C.Structure):
     _fields_ = [("episodes", _i32), ("pose", _p), ("social", _p), ("pose_count", C.c_uint64), ("social_count", C.c_uint64)]
 
@@ -127,7 +131,7 @@ def bind_buffer(struct, names, name, tensor):
 
 
 EXPORTS = [
-    "smx_create", "smx_load_map", "smx_set_vias", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
+    "smx_create", "smx_load_map", "smx_set_vias", "smx_set_missions", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
     "smx_check_buffers", "smx_set_launch_strategy",
 ]
@@ -183,6 +187,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_step_continuous.restype = C.c_int
     lib.smx_set_vias.argtypes = [h, C.POINTER(SmxVia), _i32, C.POINTER(_i32)]
     lib.smx_set_vias.restype = C.c_int
+    lib.smx_set_missions.argtypes = [h, C.POINTER(SmxMission), _i32, C.POINTER(_i32), _i32]
+    lib.smx_set_missions.restype = C.c_int
     lib.smx_step_trajectory.argtypes = [h, _p, _p, C.POINTER(SmxState), C.POINTER(SmxSpawns), C.POINTER(SmxOutputs), _p]
     lib.smx_step_trajectory.restype = C.c_int
     lib.smx_read_phase_ms.argtypes = [h, C.POINTER(C.c_float), _i32, C.POINTER(_i32)]

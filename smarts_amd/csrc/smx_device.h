@@ -12,8 +12,14 @@
 #define SMX_TWO_PI 6.283185307179586
 #define SMX_HALF_PI 1.5707963267948966
 
-// Device copy of smx_map_tables: same fields, device pointers.
-typedef smx_map_tables MapDev;
+// Device copy of smx_map_tables: same fields, device pointers — plus the route table of the agents' missions
+// (smx_set_missions), which rides with the map so that a route filter stays three words.
+struct MapDev : smx_map_tables {
+  const int16_t* route_pos;      // [slots][n_roads]: position of a road in the slot's route, -1 = not on it; may be null
+  const uint8_t* route_lane_ok;  // [slots][n_lanes]: may a path of the slot's route continue onto this lane (lanepoints.py:666-683)
+  MapDev() = default;
+  MapDev(const smx_map_tables& t) : smx_map_tables(t), route_pos(nullptr), route_lane_ok(nullptr) {}
+};
 
 // Developer build (-DSMX_DEBUG_BOUNDS): every table index is checked; the first violation's site
 // code and value are recorded instead of faulting.

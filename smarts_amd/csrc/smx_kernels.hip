@@ -68,6 +68,7 @@ struct KernelArgs {
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
   double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
   KnotLists knots;          // library-owned hand-off: k_wp_walk -> k_waypoints_tables
+  MissionsDev missions;     // device copy of smx_set_missions (null pointers: every mission endless)
   int32_t* status;          // library-owned device word of SMX_DEVICE_* bits, read and cleared by smx_sync
 };
 enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 was met (and treated as "no action")
@@ -189,6 +190,19 @@ __device__ __forceinline__ PathSeeds load_seeds(const KernelArgs& a, size_t gid,
   s.start[2] = c[7 * total + gid];
   s.start[3] = c[8 * total + gid];
   return s;
+}
+
+// TripMeterSensor.append_waypoint_if_new's should_count_wp (sensors.py:908-913): with a fixed route only waypoints
+// on the route's roads count.  The first waypoint of the first path lies on the seed road: with the waypoints
+// sensor that is one of the route's roads by construction (_waypoint_paths_along_route); without it the path
+// comes from the unrouted lookahead-1 query (sensors.py:271-275), whose start lanepoint is SMX_FI_OBS_START.
+__device__ __forceinline__ bool trip_counts_waypoint(const KernelArgs& a, const MapDev& m, size_t gid, size_t total) {
+  RouteFilter f;
+  if (!f.fixed_route(a.missions, (int)(gid % (size_t)a.cfg.num_vehicles), m.n_roads)) return true;
+  if (a.cfg.sensors & SMX_SENSOR_WAYPOINTS) return true;
+  const int os = a.st.facts_i32[(size_t)SMX_FI_OBS_START * total + gid];
+  if (os < 0) return true;  // no waypoint this tick anyway
+  return f.has(m, m.lane_road[m.lp_rec[os].lane]);
 }
 
 __device__ __forceinline__ VehState load_vehicle(const KernelArgs& a, size_t gid, size_t total) {
@@ -1029,13 +1043,13 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   }
   SMX_TSTAMP(ts4b);
   SMX_TACC(9, ts4, ts4b);
-  const PathSeeds seed = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, 5.0, true, t, sc);
+  const PathSeeds seed = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, 5.0, true, t, sc, a.missions, (int)(gid % (size_t)c.num_vehicles));
   // without the waypoints sensor the observation still takes the first waypoint of
   // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
   // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
   int obs_start = -1, trip_start = -1;
   if (!wp_on || (flags & SMX_F_FIRST)) {
-    const PathSeeds ts = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc);
+    const PathSeeds ts = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc, a.missions, 0);
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }
@@ -1191,7 +1205,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
       BranchState bs;
       bs.reset();
       RouteFilter nof;
-      nof.n = 0;
+      nof.none();
       equally_spaced_path(m, nof, bs, os, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
         have_first_wp = true;
         fwx = w.x;
@@ -1354,7 +1368,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
       BranchState bs;
       bs.reset();
       RouteFilter nof;
-      nof.n = 0;
+      nof.none();
       equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
         SF(SMX_S_TRIP_X) = w.x;
         SF(SMX_S_TRIP_Y) = w.y;
@@ -1365,7 +1379,7 @@ __device__ __forceinline__ void waypoints_for(const KernelArgs& a, const size_t 
     dist = 0.0;
   }
   const double last_dist = dist;
-  if (have_first_wp) {
+  if (have_first_wp && trip_counts_waypoint(a, m, gid, total)) {
     if (!trip_has_wp) {
       SF(SMX_S_TRIP_X) = fwx;
       SF(SMX_S_TRIP_Y) = fwy;
@@ -1500,7 +1514,7 @@ __device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const Map
       BranchState bs;
       bs.reset();
       RouteFilter nof;
-      nof.n = 0;
+      nof.none();
       equally_spaced_path(m, nof, bs, ts, 1, px, py, knots, KSTRIDE, 1, [&](int, const WaypointOut& w) {
         SF(SMX_S_TRIP_X) = w.x;
         SF(SMX_S_TRIP_Y) = w.y;
@@ -1511,7 +1525,7 @@ __device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const Map
     dist = 0.0;
   }
   const double last_dist = dist;
-  if (have_first_wp) {
+  if (have_first_wp && trip_counts_waypoint(a, m, gid, total)) {
     if (!trip_has_wp) {
       SF(SMX_S_TRIP_X) = fwx;
       SF(SMX_S_TRIP_Y) = fwy;
@@ -1568,7 +1582,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
         bs.reset();
         int below16 = 0;        // knots less than 16 hops down
         bool knot_at_16 = false;
-        const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, SMX_CTRL_WPS - 1, [&](int k, int idx, int hop) {
+        const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [&](int k, int idx, int hop) {
           if (k <= SMX_WPK_CAP) a.knots.idx[(size_t)k * paths + path] = idx;
           if (hop < SMX_CTRL_WPS - 1) ++below16;
           if (hop == SMX_CTRL_WPS - 1) knot_at_16 = true;
@@ -1579,13 +1593,22 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
         // the lookahead-16 path: the whole path when it is no longer than that, else the knots less than 16
         // hops down and the lanepoint 16 hops down (a knot of the list, or the probed interpolated lanepoint)
         a.knots.nk16[path] = (uint8_t)(w.n <= SMX_CTRL_WPS ? w.nk : below16 + 1);
-        a.knots.end16[path] = (w.n > SMX_CTRL_WPS && !knot_at_16) ? w.probe : -1;
+        // (found by a walk of its own, a handful of knot steps: noting it from inside the long walk — a probe in
+        // KnotWalk::next — made hipcc 7.2.0 drop the walk step the probe fired in on gfx950 whenever a route filter
+        // left one of several successors: profiles/r02_next0_investigation.txt, case 2)
+        int end16 = -1;
+        if (w.n > SMX_CTRL_WPS && !knot_at_16) {
+          BranchState b16;
+          b16.reset();
+          walk_knots(m, seed.f, b16, start, SMX_CTRL_WPS - 1, px, py, [&](int, int idx, int) { end16 = idx; });
+        }
+        a.knots.end16[path] = end16;
         a.knots.key[path] = start;
         a.knots.key[paths + path] = seed.f.n > 0 ? seed.f.road[0] : -1;
         a.knots.key[2 * paths + path] = seed.f.n > 1 ? seed.f.road[1] : -1;
         cnt = 1;
         while (bs.advance()) {
-          walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, -1, [](int, int, int) {});
+          walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [](int, int, int) {});
           if (cnt < 255) ++cnt;
         }
       }
@@ -1625,7 +1648,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   PathSeeds seed;
   seed.road = -1;
   seed.n_lanes = 0;
-  seed.f.n = 0;
+  seed.f.none();
   int n_first = 0, nk = 0, cnt = 0;
   double D = 0.0;
   if (live) {
@@ -2287,13 +2310,21 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     }
 
     // ---- events + done (sensors.py:443-489)
-    const bool reached_goal = false;                                   // EndlessGoal (plan.py:76-84)
+    // Mission.is_complete -> PositionalGoal.is_reached (plan.py:116-120, 220-222); EndlessGoal never (:76-84)
+    RouteFilter route;
+    const bool fixed_route = route.fixed_route(a.missions, slot, m.n_roads);
+    bool reached_goal = false;
+    if (fixed_route) {
+      const double gx = a.missions.goal[3 * slot], gy = a.missions.goal[3 * slot + 1], gr = a.missions.goal[3 * slot + 2];
+      const double sqr_dist = (s.x - gx) * (s.x - gx) + (s.y - gy) * (s.y - gy);
+      reached_goal = sqr_dist <= gr * gr;
+    }
     const bool is_off_road = !(my_facts & SMX_FACT_ON_ROAD);           // sensors.py:498-500
     const bool is_on_shoulder = ((my_facts >> SMX_FACT_CORNER_SHIFT) & 15) != 15;  // sensors.py:502-509
     const bool reached_max = c.max_episode_steps > 0 && steps >= c.max_episode_steps;
     bool is_off_route, is_wrong_way;
     {
-      // sensors.py:527-594 with no route roads (endless mission)
+      // sensors.py:527-594
       double radius = sqrt(SMX_CHASSIS_LENGTH * SMX_CHASSIS_LENGTH + SMX_CHASSIS_WIDTH * SMX_CHASSIS_WIDTH) * 0.5 + 5.0;
       int nl = (my_lane >= 0 && my_lane_dist < radius) ? my_lane : -1;
       if (nl < 0) {
@@ -2306,6 +2337,10 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
           const double target = a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid];  // k_scan
           is_wrong_way = fabs(heading_relative_to(s.heading, target)) > 0.5 * SMX_PI;
         }
+        // an endless mission has no route roads: on route (:556-561); else the nearest lane's road must be
+        // one of them, or a junction, or the lane has an oncoming neighbour that is (:563-574)
+        if (fixed_route && !route.has(m, m.lane_road[nl]) && !m.lane_in_junction[nl])
+          is_off_route = !oncoming_lane_on_route(m, route, nl, lane_offset_along(m, nl, s.x, s.y));
       }
     }
     unsigned char* ev = stage.events[local];
@@ -3051,6 +3086,9 @@ struct smx_handle_s {
   smx_via* vias_dev;
   int32_t* via_off_dev;
   int32_t n_vias;
+  void* missions_blob;      // device copy of smx_set_missions: goals | last roads | route positions | lane table
+  std::vector<int32_t> host_lane_road, host_lane_out_off, host_lane_out_idx;  // kept for smx_set_missions
+  MissionsDev missions;
   double heading_gain_pos, lateral_gain_pos;
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
@@ -3141,6 +3179,10 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->vias_dev = nullptr;
   h->via_off_dev = nullptr;
   h->n_vias = 0;
+  h->missions_blob = nullptr;
+  h->missions = MissionsDev{nullptr, nullptr};
+  h->map.route_pos = nullptr;
+  h->map.route_lane_ok = nullptr;
   h->launch_strategy = SMX_LAUNCH_AUTO;
   h->debug_skip = 0;
 #ifdef SMX_DEBUG_TIMING
@@ -3285,6 +3327,13 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   char* base = (char*)h->map_blob;
   MapDev& m = h->map;
   m = *t;  // scalars; every pointer is re-pointed into the device blob below
+  h->host_lane_road.assign(t->lane_road, t->lane_road + nl);
+  h->host_lane_out_off.assign(t->lane_out_off, t->lane_out_off + nl + 1);
+  h->host_lane_out_idx.assign(t->lane_out_idx, t->lane_out_idx + t->lane_out_off[nl]);
+  // missions name roads of the map they were set for: a new map starts without any
+  if (h->missions_blob) (void)hipFree(h->missions_blob);
+  h->missions_blob = nullptr;
+  h->missions = MissionsDev{nullptr, nullptr};
 #define PTR(field, type) m.field = (const type*)(base + off_##field)
   PTR(lane_road, int32_t);
   PTR(lane_index, int32_t);
@@ -3386,6 +3435,82 @@ extern "C" int smx_set_vias(smx_handle h, const smx_via* vias_host, int32_t n, c
   SMX_HIP(hipMemcpy(h->vias_dev, vias_host, (size_t)n * sizeof(smx_via), hipMemcpyHostToDevice));
   SMX_HIP(hipMemcpy(h->via_off_dev, slot_off_host, (size_t)(nv + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
   h->n_vias = n;
+  return SMX_OK;
+}
+
+extern "C" int smx_set_missions(smx_handle h, const smx_mission* missions_host, int32_t n_slots,
+                                const int32_t* route_roads_host, int32_t n_route_roads) {
+  if (!h) return SMX_ERR_INVALID;
+  if (!h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_set_missions needs the map (road indices are checked)");
+  if (n_slots < 0 || n_route_roads < 0 || (n_slots > 0 && !missions_host) || (n_route_roads > 0 && !route_roads_host))
+    return fail(h, SMX_ERR_INVALID, "smx_set_missions: null table");
+  const int nv = h->cfg.num_vehicles, nr = h->map.n_roads;
+  if (n_slots != 0 && n_slots != nv) return fail(h, SMX_ERR_INVALID, "smx_set_missions: one mission per vehicle slot (cfg.num_vehicles)");
+  if ((size_t)nv * (size_t)nr > 0x7fffffffull) return fail(h, SMX_ERR_INVALID, "smx_set_missions: slots x roads too large");
+  const int nl = h->map.n_lanes;
+  std::vector<int16_t> pos((size_t)n_slots * nr, (int16_t)-1);
+  std::vector<uint8_t> lane_ok((size_t)n_slots * nl, (uint8_t)0);
+  std::vector<int32_t> last((size_t)n_slots, -1);
+  std::vector<double> goal((size_t)n_slots * 3, 0.0);
+  bool any = false;
+  for (int s = 0; s < n_slots; ++s) {
+    const smx_mission& ms = missions_host[s];
+    if (ms.route_len == 0) continue;  // endless mission: empty route (plan.py:321-323)
+    if (ms.route_len < 0 || ms.route_len > 32767 || ms.route_off < 0 || (int64_t)ms.route_off + ms.route_len > n_route_roads)
+      return fail(h, SMX_ERR_INVALID, "smx_set_missions: route range outside route_roads (at most 32767 roads)");
+    if (!(ms.goal_radius >= 0.0) || !std::isfinite(ms.goal_x) || !std::isfinite(ms.goal_y))
+      return fail(h, SMX_ERR_INVALID, "smx_set_missions: a fixed route needs a PositionalGoal (finite position, radius >= 0)");
+    for (int k = 0; k < ms.route_len; ++k) {
+      const int road = route_roads_host[ms.route_off + k];
+      if (road < 0 || road >= nr) return fail(h, SMX_ERR_INVALID, "smx_set_missions: road index out of range");
+      int16_t& p = pos[(size_t)s * nr + road];
+      if (p < 0) p = (int16_t)k;  // first occurrence: `min` over the route keeps the first minimum
+    }
+    last[s] = route_roads_host[ms.route_off + ms.route_len - 1];
+    // lanepoints.py:666-683 per lane (the rule lane_allowed evaluates for the short in-junction lists): on a road
+    // of the route, and — unless that is the route's last road — leading on to a road of the route
+    const int16_t* on = &pos[(size_t)s * nr];
+    for (int lane = 0; lane < nl; ++lane) {
+      const int road = h->host_lane_road[lane];
+      bool ok = on[road] >= 0;
+      if (ok && road != last[s]) {
+        bool any = false;
+        for (int k = h->host_lane_out_off[lane]; k < h->host_lane_out_off[lane + 1]; ++k)
+          any = any || on[h->host_lane_road[h->host_lane_out_idx[k]]] >= 0;
+        ok = any;
+      }
+      lane_ok[(size_t)s * nl + lane] = ok ? 1 : 0;
+    }
+    goal[3 * s] = ms.goal_x;
+    goal[3 * s + 1] = ms.goal_y;
+    goal[3 * s + 2] = ms.goal_radius;
+    any = true;
+  }
+  SMX_HIP(hipSetDevice(h->device));
+  SMX_HIP(hipDeviceSynchronize());  // launches in flight still read the old table
+  if (h->missions_blob) (void)hipFree(h->missions_blob);
+  h->missions_blob = nullptr;
+  h->missions = MissionsDev{nullptr, nullptr};
+  h->map.route_pos = nullptr;
+  h->map.route_lane_ok = nullptr;
+  // the knot lists of the previous tick were walked under the old routes
+  if (h->knots_blob && h->knots.key)
+    SMX_HIP(hipMemset(h->knots.key, 0xff, 3 * (size_t)h->cfg.num_envs * nv * SMX_WP_LANES * sizeof(int32_t)));
+  if (!any) return SMX_OK;
+  const size_t goal_bytes = goal.size() * sizeof(double), last_bytes = last.size() * sizeof(int32_t),
+               pos_bytes = pos.size() * sizeof(int16_t);
+  const size_t off_last = goal_bytes, off_pos = (goal_bytes + last_bytes + 7) & ~(size_t)7;
+  const size_t off_lane = (off_pos + pos_bytes + 7) & ~(size_t)7;
+  SMX_HIP(hipMalloc(&h->missions_blob, off_lane + lane_ok.size()));
+  char* base = (char*)h->missions_blob;
+  SMX_HIP(hipMemcpy(base, goal.data(), goal_bytes, hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy(base + off_last, last.data(), last_bytes, hipMemcpyHostToDevice));
+  SMX_HIP(hipMemcpy(base + off_pos, pos.data(), pos_bytes, hipMemcpyHostToDevice));
+  h->missions.goal = (const double*)base;
+  h->missions.route_last = (const int32_t*)(base + off_last);
+  SMX_HIP(hipMemcpy(base + off_lane, lane_ok.data(), lane_ok.size(), hipMemcpyHostToDevice));
+  h->map.route_pos = (const int16_t*)(base + off_pos);
+  h->map.route_lane_ok = (const uint8_t*)(base + off_lane);
   return SMX_OK;
 }
 
@@ -3560,6 +3685,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.env_mask = mask;
   a.lidar_rays = h->lidar_rays;
   a.vias = h->n_vias > 0 ? h->vias_dev : nullptr;
+  a.missions = h->missions;
   a.via_slot_off = h->via_off_dev;
   a.first_only = 0;
   a.keep_reward_done = 0;
@@ -3879,6 +4005,7 @@ extern "C" void smx_destroy(smx_handle h) {
   }
   if (h->vias_dev) (void)hipFree(h->vias_dev);
   if (h->via_off_dev) (void)hipFree(h->via_off_dev);
+  if (h->missions_blob) (void)hipFree(h->missions_blob);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ph_pool) (void)hipEventDestroy(e);
   delete h;

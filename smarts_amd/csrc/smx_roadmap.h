@@ -283,25 +283,57 @@ __device__ inline void closest_filtered4(const MapDev& m, double px, double py, 
 // ---------------------------------------------------------------------------------
 // lanepoint paths (lanepoints.py:646-692)
 // ---------------------------------------------------------------------------------
+// Missions of the agent slots (smx_set_missions), device side.  Null pointers: every mission is endless.
+struct MissionsDev {
+  const int32_t* route_last;  // [slots]: last road of the route (lanepoints.py:674), -1 = endless mission (empty route)
+  const double* goal;         // [slots][3]: PositionalGoal x, y, radius
+};
+
 // Route filter: the road ids of _resolve_in_junction (at most the junction road and the
-// road it leads to), or none.
+// road it leads to), the roads of a mission's fixed route, or none.
+#define SMX_ROUTE_FIXED 3
 struct RouteFilter {
-  int n;  // 0 = no filter
+  int n;  // 0 = no filter; 1, 2 = the list road[]; SMX_ROUTE_FIXED = a fixed route: road[0] = the agent slot (row of
+          // MapDev::route_pos / route_lane_ok), road[1] = the route's last road
   int road[2];
-  __device__ __forceinline__ bool has(int r) const { return (n > 0 && road[0] == r) || (n > 1 && road[1] == r); }
-  __device__ __forceinline__ int last() const { return road[n - 1]; }
+  __device__ __forceinline__ bool has(const MapDev& m, int r) const {
+    if (n == SMX_ROUTE_FIXED) return m.route_pos[road[0] * m.n_roads + r] >= 0;
+    return (n > 0 && road[0] == r) || (n > 1 && road[1] == r);
+  }
+  __device__ __forceinline__ int last() const { return n == SMX_ROUTE_FIXED ? road[1] : road[n - 1]; }
+  __device__ __forceinline__ void none() {
+    n = 0;
+    road[0] = road[1] = -1;
+  }
+  // the filter of agent slot `slot`'s mission; false (and no filter) if that mission is endless
+  __device__ __forceinline__ bool fixed_route(const MissionsDev& ms, int slot, int n_roads) {
+    none();
+    if (ms.route_last == nullptr) return false;
+    const int last_road = ms.route_last[slot];
+    if (last_road < 0) return false;
+    n = SMX_ROUTE_FIXED;
+    road[0] = slot;
+    road[1] = last_road;
+    (void)n_roads;
+    return true;
+  }
 };
 
 // lanepoints.py:666-683: may a path continue onto a lanepoint of `lane`?  (A pure function of
 // the lane, so a walk is checked where the lane changes, not per hop.)
+// For a fixed route the answer per (slot, lane) is tabulated by smx_set_missions (the same rule, evaluated once
+// on the host: host_lane_allowed in smx_kernels.hip).
 __device__ __forceinline__ bool lane_allowed(const MapDev& m, const RouteFilter& f, int lane) {
   if (f.n == 0) return true;
+#ifndef SMX_ROUTE_RULE_ON_DEVICE
+  if (f.n == SMX_ROUTE_FIXED) return m.route_lane_ok[f.road[0] * m.n_lanes + lane] != 0;
+#endif
   const int road = m.lane_road[SMX_BCHK(14, lane, m.n_lanes)];
-  if (!f.has(road)) return false;
+  if (!f.has(m, road)) return false;
   if (road != f.last()) {
     bool any = false;
     for (int k = m.lane_out_off[lane]; k < m.lane_out_off[lane + 1]; ++k)
-      any = any || f.has(m.lane_road[m.lane_out_idx[k]]);
+      any = any || f.has(m, m.lane_road[m.lane_out_idx[k]]);
     if (!any) return false;
   }
   return true;
@@ -352,8 +384,6 @@ struct KnotWalk {
   smx_lp_rec cur; // record of the lanepoint the walk stands on
   bool start;     // still on the start point (its own lane has not been checked by the filter)
   int cur_idx;    // index of `cur`
-  int probe_hop;  // -1, or a hop count: the lanepoint the path reaches after that many hops is noted in probe_idx
-  int probe_idx;  // (-1 while the path has not got that far) — where a path of that shorter lookahead would end
 
   __device__ __forceinline__ void begin(const MapDev& m, int start_lp, int lookahead) {
     remaining = lookahead;
@@ -362,17 +392,6 @@ struct KnotWalk {
     cur = load_lp(m, start_lp, 40);
     cur_idx = start_lp;
     start = true;
-    probe_hop = -1;
-    probe_idx = -1;
-  }
-
-  // the step from hop n - 1 covers `adv` hops along the run that starts at `first` (the knot itself when it is
-  // reached: at_knot): note the lanepoint at probe_hop if it lies on this stretch
-  __device__ __forceinline__ void probe(const MapDev& m, int first, int adv, int hops, int knot, bool at_knot, bool consecutive) {
-    if (probe_hop >= n && probe_hop <= n - 1 + adv) {
-      const int delta = probe_hop - (n - 1);
-      probe_idx = (at_knot && delta == hops) ? knot : chain_at(m, first_of_run(m, first), delta - 1, consecutive);
-    }
   }
 
   __device__ __forceinline__ int first_of_run(const MapDev& m, int first) const {
@@ -397,37 +416,39 @@ struct KnotWalk {
       hops = cur.knot_hops;
       first_lane = -1;  // same lane as `cur` when interpolated, else the knot's own lane
     } else {
-      int allowed = 0;
+      // one pass over the successors: count the allowed ones, remember the first allowed and — where this level's
+      // choice is already fixed (an earlier leaf of the enumeration) — the chosen one
       const int a = cur.next_off, b = a + cur.n_next;
-      for (int k = a; k < b; ++k) allowed += lane_allowed(m, f, m.succ_rec[SMX_BCHK(15, k, m.n_succ)].lane) ? 1 : 0;
+      const bool fixed = level < bs.nb;
+      const int want = fixed ? bs.get_choice(level) : 0;  // meaningful only if several are allowed
+      int allowed = 0;
+      smx_succ_rec s0, sw;
+      s0.idx = sw.idx = -1;
+      s0.knot = sw.knot = -1;
+      s0.hops = sw.hops = 0;
+      s0.lane = sw.lane = -1;
+      for (int k = a; k < b; ++k) {
+        const smx_succ_rec sr = m.succ_rec[SMX_BCHK(15, k, m.n_succ)];
+        if (!lane_allowed(m, f, sr.lane)) continue;
+        if (allowed == 0) s0 = sr;
+        if (allowed == want) sw = sr;
+        ++allowed;
+      }
       if (allowed == 0) return -1;
-      int want = 0;
+      smx_succ_rec take = s0;
       if (allowed > 1) {
-        if (level < bs.nb) {
-          want = bs.get_choice(level);
+        if (fixed) {
+          take = sw;
         } else if (level < 16) {
           bs.set(level, 0, min(allowed, 15));
           bs.nb = level + 1;
         }
         ++level;
       }
-      int seen = 0;
-      first = -1;
-      knot = -1;
-      hops = 0;
-      first_lane = -1;
-      for (int k = a; k < b; ++k) {
-        const smx_succ_rec sr = m.succ_rec[k];
-        if (!lane_allowed(m, f, sr.lane)) continue;
-        if (seen == want) {
-          first = sr.idx;
-          knot = sr.knot;
-          hops = sr.hops;
-          first_lane = sr.lane;
-          break;
-        }
-        ++seen;
-      }
+      first = take.idx;
+      knot = take.knot;
+      hops = take.hops;
+      first_lane = take.lane;
       if (first < 0) return -1;
     }
     const bool consecutive = (cur.flags & 1) != 0;
@@ -438,7 +459,6 @@ struct KnotWalk {
       // arriving on the knot is a hop onto its lane
       const bool ok = (hops > 1 || cur.n_next == 1 || first_lane == rec.lane) ? lane_allowed(m, f, rec.lane) : true;
       if (ok) {
-        probe(m, first, hops, hops, knot, true, consecutive);
         remaining -= hops;
         n += hops;
         cur = rec;
@@ -452,7 +472,6 @@ struct KnotWalk {
       if (hops == 1) return -1;
       // the knot's lane is closed: the path stops on the interpolated point before it
       const int fin = chain_at(m, first_of_run(m, first), hops - 2, consecutive);
-      probe(m, first, hops - 1, hops, knot, false, consecutive);
       rec = load_lp(m, fin, 42);
       n += hops - 1;
       remaining = 0;
@@ -474,7 +493,6 @@ struct KnotWalk {
       smx_dbg_aux[7] = ((const volatile smx_lp_rec*)m.lp_rec)[cur_idx].next0;
     }
 #endif
-    probe(m, first, remaining, hops, knot, false, consecutive);
     rec = load_lp(m, fin, 43);
     n += remaining;
     remaining = 0;
@@ -804,17 +822,15 @@ struct PathWalk {
   int n;      // lanepoints on the path
   int nk;     // knots after entry 0
   double D;   // arclength over all knots
-  int probe;  // the lanepoint `probe_hop` hops down the path, -1 if it is shorter
 };
 
 // Pass 1 of equally_spaced_path: sink(k, lanepoint index, hops from the start) is called for every knot
 // k = 1..nk in path order.
 template <class Sink>
 __device__ inline PathWalk walk_knots(const MapDev& m, const RouteFilter& f, BranchState& bs, int start, int lookahead,
-                                      double px, double py, int probe_hop, Sink&& sink) {
+                                      double px, double py, Sink&& sink) {
   KnotWalk w;
   w.begin(m, start, lookahead);
-  w.probe_hop = probe_hop;
   const smx_lp_rec r0 = w.cur;
   const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
   PathWalk out;
@@ -834,7 +850,6 @@ __device__ inline PathWalk walk_knots(const MapDev& m, const RouteFilter& f, Bra
     sink(out.nk, idx, w.n - 1);
   }
   out.n = w.n;
-  out.probe = w.probe_idx;
   return out;
 }
 
@@ -850,12 +865,59 @@ struct PathSeeds {
   int start[SMX_SEED_LANES];   // start lanepoint per lane (first SMX_SEED_LANES lanes)
 };
 
+// _waypoint_paths_along_route's seed (sumo_road_network.py:862-876): closest_linked_lanepoint_on_road for every
+// road of the route, then the first minimum of np.linalg.norm(position - point) in route order.  One sweep:
+// candidates ordered by (sqrt(d2), position of the road in the route, d2, lanepoint index) — within a road
+// that is the KD-tree's minimum of d2 (index ties, DESIGN.md deviation 1), across roads the first minimum.
+struct RouteBest {
+  double d, d2;
+  int pos, idx;
+  __device__ __forceinline__ void none() {
+    d = d2 = SMX_INF;
+    pos = idx = 0x7fffffff;
+  }
+  __device__ __forceinline__ bool worse_than(double od, int opos, double od2, int oidx) const {
+    if (od != d) return od < d;
+    if (opos != pos) return opos < pos;
+    if (od2 != d2) return od2 < d2;
+    return oidx < idx;
+  }
+  __device__ __forceinline__ void offer(const MapDev& m, const RouteFilter& f, const smx_pt_rec& p, double px, double py) {
+    const int rp = m.route_pos[f.road[0] * m.n_roads + m.lane_road[p.lane]];
+    if (rp < 0) return;
+    const double dx = p.x - px, dy = p.y - py;
+    const double q2 = dx * dx + dy * dy;
+    const double q = sqrt(q2);
+    if (worse_than(q, rp, q2, p.idx)) {
+      d = q;
+      d2 = q2;
+      pos = rp;
+      idx = p.idx;
+    }
+  }
+};
+
+__device__ inline int closest_on_route(const MapDev& m, const RouteFilter& f, double px, double py) {
+  RouteBest b;
+  b.none();
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int rmax = lp_max_ring(m, cx, cy);
+  for (int r = 0; r <= rmax; ++r) {
+    lp_ring_visit(m, cx, cy, r, [&](const smx_pt_rec& p) { b.offer(m, f, p, px, py); });
+    if (b.idx != 0x7fffffff && ring_covers(m, r, b.d2)) break;
+  }
+  return b.idx == 0x7fffffff ? -1 : b.idx;
+}
+
 // has_route_object: the agent carries a (possibly empty) Route — the controller and the
-// waypoints sensor do; TripMeterSensor's constructor query does not.
+// waypoints sensor do; TripMeterSensor's constructor query does not.  `ms`, `slot`: the missions
+// table and the agent's slot (a fixed route replaces the in-junction rule: sumo_road_network.py:822-829).
 __device__ inline PathSeeds compute_path_seeds(const MapDev& m, double px, double py, double heading,
-                                               double within_radius, bool has_route_object) {
+                                               double within_radius, bool has_route_object,
+                                               const MissionsDev* ms = nullptr, int slot = 0) {
   PathSeeds s;
-  s.f.n = 0;
+  s.f.none();
   s.road = -1;
   s.n_lanes = 0;
 #pragma unroll
@@ -863,7 +925,11 @@ __device__ inline PathSeeds compute_path_seeds(const MapDev& m, double px, doubl
   Top10 t;
   nearest10(m, px, py, t);
   bool routed = false;
-  if (has_route_object) {
+  if (has_route_object && ms != nullptr && s.f.fixed_route(*ms, slot, m.n_roads)) {
+    const int best = closest_on_route(m, s.f, px, py);
+    s.road = best >= 0 ? m.lane_road[m.lp_rec[best].lane] : -1;
+    routed = true;
+  } else if (has_route_object) {
     // _resolve_in_junction (:842-860)
     int lp = pick_closest(m, t, heading, -1.0);
     if (lp >= 0) {

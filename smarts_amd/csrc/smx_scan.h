@@ -350,21 +350,54 @@ __device__ inline Top10Scores team_top10_heading_terms(const MapDev& m, const To
   return sc;
 }
 
+// closest_on_route (smx_roadmap.h), the ring cells strided over the team
+template <int TEAM>
+__device__ inline int team_closest_on_route(const MapDev& m, const RouteFilter& f, double px, double py) {
+  RouteBest b;
+  b.none();
+  const int rank = team_rank<TEAM>();
+  const int cx = (int)floor((px - m.lpg_x0) / m.lpg_cell);
+  const int cy = (int)floor((py - m.lpg_y0) / m.lpg_cell);
+  const int rmax = lp_max_ring(m, cx, cy);
+  RouteBest all;
+  all.none();
+  for (int r = 0; r <= rmax; ++r) {
+    lp_ring_visit_team<TEAM>(m, cx, cy, r, rank, [&](const smx_pt_rec& p) { b.offer(m, f, p, px, py); });
+    all = b;
+#pragma unroll
+    for (int msk = TEAM / 2; msk >= 1; msk >>= 1) {
+      const double od = __shfl_xor(all.d, msk, TEAM), od2 = __shfl_xor(all.d2, msk, TEAM);
+      const int opos = __shfl_xor(all.pos, msk, TEAM), oidx = __shfl_xor(all.idx, msk, TEAM);
+      if (all.worse_than(od, opos, od2, oidx)) {
+        all.d = od;
+        all.d2 = od2;
+        all.pos = opos;
+        all.idx = oidx;
+      }
+    }
+    if (all.idx != 0x7fffffff && ring_covers(m, r, all.d2)) break;
+  }
+  return all.idx == 0x7fffffff ? -1 : all.idx;
+}
+
 // compute_path_seeds, team form (see smx_roadmap.h for the semantics)
 template <int TEAM>
 __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
                                                     double within_radius, bool has_route_object, const Top10& t,
-                                                    const Top10Scores& sc) {
+                                                    const Top10Scores& sc, const MissionsDev& ms, int slot) {
   PathSeeds s;
-  s.f.n = 0;
-  s.f.road[0] = s.f.road[1] = -1;
+  s.f.none();
   s.road = -1;
   s.n_lanes = 0;
 #pragma unroll
   for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
   bool routed = false;
   SMX_TSTAMP(tp0);
-  if (has_route_object) {
+  if (has_route_object && s.f.fixed_route(ms, slot, m.n_roads)) {
+    const int best = team_closest_on_route<TEAM>(m, s.f, px, py);
+    s.road = best >= 0 ? m.lane_road[m.lp_rec[best].lane] : -1;
+    routed = true;
+  } else if (has_route_object) {
     int lp = pick_closest(t, sc, -1.0);
     if (lp >= 0) {
       int road = m.lane_road[m.lp_rec[lp].lane];
@@ -550,6 +583,126 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
 }
 
+
+// ---------------------------------------------------------------------------------
+// One-lane (serial) forms for the rare questions of the event code: offset_along_lane
+// (sumo_road_network.py:476-491), from_lane_coord (:502-506, s only), vector_at_offset (road_map.py:377-388).
+// Same arithmetic as the team forms above.
+// ---------------------------------------------------------------------------------
+__device__ inline double lane_offset_along(const MapDev& m, int lane, double px, double py) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  for (int v = v0; v < v1; ++v) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.x == px && a.y == py) return a.cum;
+  }
+  double min_dist = SMX_INF, offset = -1.0;
+  for (int v = v0; v + 1 < v1; ++v) {
+    const smx_shape_rec a = m.shape_rec[v], b = m.shape_rec[v + 1];
+    const double gx = fmax(fmax(fmin(a.x, b.x) - px, px - fmax(a.x, b.x)), 0.0);
+    const double gy = fmax(fmax(fmin(a.y, b.y) - py, py - fmax(a.y, b.y)), 0.0);
+    const double keep = min_dist + 1e-6;
+    if (gx * gx + gy * gy > keep * keep) continue;
+    const double d = a.len;
+    const double u = ((px - a.x) * (b.x - a.x)) + ((py - a.y) * (b.y - a.y));
+    const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+    double fx, fy;
+    position_at_offset(a.x, a.y, b.x, b.y, d, poff, fx, fy);
+    const double dist = euclid(px, py, fx, fy);
+    if (dist < min_dist) {
+      min_dist = dist;
+      offset = poff + a.cum;
+    }
+  }
+  return offset;
+}
+
+__device__ inline void lane_point_at_offset(const MapDev& m, int lane, double offset, double& ox, double& oy) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  for (int v = v0; v + 1 < v1; ++v) {
+    const smx_shape_rec a = m.shape_rec[v];
+    if (a.cum + a.len > offset) {
+      const smx_shape_rec b = m.shape_rec[v + 1];
+      position_at_offset(a.x, a.y, b.x, b.y, a.len, offset - a.cum, ox, oy);
+      return;
+    }
+  }
+  const smx_shape_rec z = m.shape_rec[v1 - 1];
+  ox = z.x;
+  oy = z.y;
+}
+
+__device__ inline void lane_vector_at_offset(const MapDev& m, int lane, double offset, double& vx, double& vy) {
+  const double L = m.lane_length[lane];
+  double s_off, e_off;
+  if (offset >= L) {
+    s_off = L - 1.0;
+    e_off = L;
+  } else {
+    s_off = offset;
+    e_off = offset + 1.0;
+  }
+  s_off = fmax(s_off, 0.0);
+  double p1x, p1y, p2x, p2y;
+  lane_point_at_offset(m, lane, s_off, p1x, p1y);
+  lane_point_at_offset(m, lane, e_off, p2x, p2y);
+  vx = p2x - p1x;
+  vy = p2y - p1y;
+}
+
+// Is one of Lane.oncoming_lanes_at_offset(offset) (sumo_road_network.py:371-395) on a road of the route?
+// (sensors.py:566-571: the vehicle may have crossed the centre line into an oncoming lane of its route.)
+// nearest_lanes(pt, radius): every lane with a centre-line segment closer than the radius, found through the
+// segment grid like road_facts_scan; a lane met through several segments is simply asked again.
+__device__ inline bool oncoming_lane_on_route(const MapDev& m, const RouteFilter& f, int lane, double offset) {
+  const double radius = 1.1 * m.lane_width[lane];
+  double ptx, pty;
+  lane_point_at_offset(m, lane, offset, ptx, pty);
+  double mvx, mvy;
+  lane_vector_at_offset(m, lane, offset, mvx, mvy);
+  const double my_norm = sqrt(mvx * mvx + mvy * mvy + 0.0);
+  if (my_norm == 0.0) return false;
+  const double threshold = -0.995562;  // cos(175 deg)
+  int cx0 = (int)floor((ptx - radius - m.sg_x0) / m.sg_cell), cx1 = (int)floor((ptx + radius - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((pty - radius - m.sg_y0) / m.sg_cell), cy1 = (int)floor((pty + radius - m.sg_y0) / m.sg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.sg_nx - 1);
+  cy1 = min(cy1, m.sg_ny - 1);
+  int asked = -1;
+  for (int gy = cy0; gy <= cy1; ++gy) {
+    const int row = gy * m.sg_nx;
+    const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
+    for (int k = a; k < b; ++k) {
+      const smx_seg_rec s = m.sg_rec[k];
+      if (s.lane == lane || s.lane == asked) continue;
+      if (!f.has(m, m.lane_road[s.lane])) continue;  // only a lane of the route can change the answer
+      // distance_point_to_line (math.py:393-411), as in road_facts_scan
+      const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
+      const double d = sqrt(ex * ex + ey * ey);
+      const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
+      const double u = ((ptx - s.x1) * sx) + ((pty - s.y1) * sy);
+      const double off = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+      double dist;
+      if (off == 0.0) {
+        dist = sqrt((ptx - s.x1) * (ptx - s.x1) + (pty - s.y1) * (pty - s.y1));
+      } else {
+        const double uu = off / d;
+        const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
+        dist = sqrt((ptx - ix) * (ptx - ix) + (pty - iy) * (pty - iy));
+      }
+      if (!(dist < radius)) continue;
+      asked = s.lane;
+      const double ls = lane_offset_along(m, s.lane, ptx, pty);
+      double lvx, lvy;
+      lane_vector_at_offset(m, s.lane, ls, lvx, lvy);
+      const double lv_norm = sqrt(lvx * lvx + lvy * lvy + 0.0);
+      if (lv_norm == 0.0) continue;
+      const double lane_angle = (mvx * lvx + mvy * lvy + 0.0) / (my_norm * lv_norm);
+      if (lane_angle < threshold) return true;
+    }
+  }
+  return false;
+}
 
 // ---------------------------------------------------------------------------------
 // Lane.center_at_point (road_map.py:357-360): from_lane_coord(offset_along_lane(point)) — the point of

@@ -177,8 +177,10 @@ class BatchedSim:
 
     def __init__(self, cm: CompiledMap, cfg: SimConfig, device: str = "cuda:0", spawns: Optional[np.ndarray] = None,
                  spawn_episodes: int = 2, seed: int = 42, first_env: int = 0, social_spawns: Optional[np.ndarray] = None,
-                 vias: Optional[Sequence[Sequence]] = None):
-        """``vias``: per agent slot, a list of ``vias.ResolvedVia`` (the missions' via points)."""
+                 vias: Optional[Sequence[Sequence]] = None, missions: Optional[Sequence] = None):
+        """``vias``: per agent slot, a list of ``vias.ResolvedVia`` (the missions' via points).
+        ``missions``: per vehicle slot ``None`` (endless mission, empty route) or a
+        ``missions.PlannedMission`` (fixed route + PositionalGoal); see ``set_missions``."""
         self.lib = nat.load_library()
         if not torch.cuda.is_available():
             raise nat.NativeLibraryError("no ROCm device visible: the smarts_amd hot path runs on the GPU only")
@@ -246,6 +248,9 @@ class BatchedSim:
                 recs[i].hit_distance, recs[i].required_speed, recs[i].lane = v.hit_distance, v.required_speed, v.lane
             offs = (C.c_int32 * (N + 1))(*np.concatenate([[0], np.cumsum([len(lst) for lst in self.vias])]).astype(int).tolist())
             nat.check(self.lib, self.handle, self.lib.smx_set_vias(self.handle, recs, len(flat), offs), "smx_set_vias")
+        self.missions = None
+        if missions is not None:
+            self.set_missions(missions)
         if cfg.lidar is not None:
             self.lidar_rays = torch.from_numpy(base_rays(cfg.lidar)).to(dev)
             rc = self.lib.smx_set_lidar_rays(self.handle, self.lidar_rays.data_ptr(), int(self.lidar_rays.shape[0]))
@@ -399,6 +404,29 @@ class BatchedSim:
         if self.cfg.lidar is not None:
             kb["sensors"] = add(kb["sensors"], (pose, o["lidar_hit"] + o["lidar_point"]))
         return kb
+
+    def set_missions(self, missions: Optional[Sequence]):
+        """Fixed-route missions per vehicle slot, shared by every env (``smx_set_missions``): ``None`` entries
+        (or ``missions=None``) are endless missions with an empty route."""
+        N = self.N
+        if missions is None or all(m is None for m in missions):
+            nat.check(self.lib, self.handle, self.lib.smx_set_missions(self.handle, None, 0, None, 0), "smx_set_missions")
+            self.missions = None
+            return
+        if len(missions) != N:
+            raise ValueError("missions: one entry per vehicle slot")
+        road_no = {rid: i for i, rid in enumerate(self.cm.road_ids)}
+        recs = (nat.SmxMission * N)()
+        roads = []
+        for s, m in enumerate(missions):
+            if m is None:
+                continue
+            recs[s].goal_x, recs[s].goal_y, recs[s].goal_radius = m.goal
+            recs[s].route_off, recs[s].route_len = len(roads), len(m.route_roads)
+            roads += [road_no[r] for r in m.route_roads]
+        arr = (C.c_int32 * max(len(roads), 1))(*roads)
+        nat.check(self.lib, self.handle, self.lib.smx_set_missions(self.handle, recs, N, arr, len(roads)), "smx_set_missions")
+        self.missions = list(missions)
 
     def small_form(self) -> bool:
         """Whether a tick runs in the SMALL launch form (smx_kernels.hip: SMX_LARGE_BATCH_VEHICLES)."""

@@ -129,7 +129,8 @@ class BatchCore:
 
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
                  auto_reset: bool, device: str = "cuda:0", waypoint_window: Optional[Tuple[int, int]] = (4, 20),
-                 num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None, social_model: str = "constant"):
+                 num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None, social_model: str = "constant",
+                 missions: Optional[Dict[str, Any]] = None):
         from ..engine import BatchedSim, make_spawns
         from ..scenario_build import load_compiled_map
 
@@ -160,8 +161,26 @@ class BatchCore:
                 raise ValueError(f"vias for unknown agents: {sorted(unknown)}")
             self.vias = [resolve_vias(self.cm, vias.get(a, ())) for a in self.agent_ids] + [[] for _ in range(num_social)]
             self.cfg.via_max = 8
+        # fixed-route missions (sstudio Mission per agent id): planned once (Scenario._extract_mission +
+        # Plan.create_route), the agent's spawn rows become the mission's start in every env and episode
+        self.missions = None
+        if missions:
+            from ..missions import plan_mission
+            from ..sumo_map import load_net
+
+            unknown = set(missions) - set(self.agent_ids)
+            if unknown:
+                raise ValueError(f"missions for unknown agents: {sorted(unknown)}")
+            net = load_net(self.scenario_dir)
+            self.missions = [plan_mission(net, missions[a]) if a in missions else None for a in self.agent_ids]
+            self.missions += [None] * num_social
+            slots = self.N + num_social
+            for i, m in enumerate(self.missions):
+                if m is not None:
+                    x, y, h = m.spawn_pose()
+                    spawns.reshape(spawns.shape[0], num_envs, slots, 4)[:, :, i] = (x, y, h, 0.0)
         self.sim = BatchedSim(self.cm, self.cfg, device=device, spawns=spawns, seed=seed, social_spawns=where,
-                              vias=self.vias)
+                              vias=self.vias, missions=self.missions)
         road_ids = [self.cm.road_ids[r] for r in self.cm.lane_road]
         vehicle_names = self.agent_ids + [f"social-{k}" for k in range(num_social)]
         self.builder = ObservationBuilder(

@@ -46,6 +46,7 @@ class HiWayEnv:
         num_social: int = 0,
         social_model: str = "constant",
         vias: Optional[Dict[str, Sequence]] = None,
+        missions: Optional[Union[Dict[str, Any], str]] = None,
     ):
         self._log = logging.getLogger(self.__class__.__name__)
         if not headless or envision_record_data_replay_path or envision_endpoint:
@@ -74,6 +75,14 @@ class HiWayEnv:
         # mission via points per agent id (smarts_amd.vias.Via = sstudio's Via); the reference reads them
         # from the scenario's missions, which this path does not parse
         self._vias = dict(vias) if vias else None
+        # fixed-route missions per agent id (smarts_amd.missions.Mission = sstudio's Mission / Route, or the path
+        # of a missions JSON): the agent starts at the route's begin, is held to the route (waypoints, off_route,
+        # trip meter) and ends at its goal (reached_goal); agents without one drive endless missions
+        if isinstance(missions, str):
+            from ..missions import load_missions
+
+            missions = load_missions(missions)
+        self._missions = dict(missions) if missions else None
         self._dones_registered = 0
         self._core: Optional[BatchCore] = None
         self._seed = seed
@@ -104,7 +113,7 @@ class HiWayEnv:
         """What must agree for envs to share one device batch (ParallelEnv)."""
         specs = self._agent_specs
         return (self._scenario, tuple(specs.keys()), tuple(repr(s.interface) for s in specs.values()), self._dt,
-                self._waypoint_window, self._num_social, self._social_model, repr(self._vias))
+                self._waypoint_window, self._num_social, self._social_model, repr(self._vias), repr(self._missions))
 
     def seed(self, seed: int) -> int:
         """hiway_env.py:204-214.  Takes effect at the next ``reset`` that (re)builds the spawn table."""
@@ -123,7 +132,8 @@ class HiWayEnv:
         if self._core is None:
             self._core = BatchCore(self._scenario, self._agent_specs, num_envs=1, dt=self._dt, seed=self._seed,
                                    auto_reset=False, device=self._device, waypoint_window=self._waypoint_window,
-                                   num_social=self._num_social, vias=self._vias, social_model=self._social_model)
+                                   num_social=self._num_social, vias=self._vias, social_model=self._social_model,
+                                   missions=self._missions)
         return self._core
 
     def step(self, agent_actions) -> Tuple[Dict[str, Observation], Dict[str, float], Dict[str, bool], Dict[str, Any]]:

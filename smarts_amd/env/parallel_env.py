@@ -63,7 +63,7 @@ class ParallelEnv:
         p = self._proto
         self._core = BatchCore(p._scenario, p.agent_specs, num_envs=self._num_envs, dt=p._dt, seed=seed,
                                auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window or STD_WAYPOINT_WINDOW,
-                               num_social=p._num_social, vias=p._vias, social_model=p._social_model)
+                               num_social=p._num_social, vias=p._vias, social_model=p._social_model, missions=p._missions)
         self._seed = seed
         return [seed + i for i in range(self._num_envs)]
 

@@ -52,3 +52,41 @@ int host_nearest_lane(const smx_map_tables* m, double px, double py, double radi
 }
 
 }  // extern "C"
+
+// waypoint_paths(pose, lookahead, route) for a fixed route (smx_set_missions' tables for one slot: route_pos
+// [n_roads], lane_ok [n_lanes], the route's last road): every path, as host_waypoint_paths.
+extern "C" int host_routed_waypoint_paths(const smx_map_tables* t, const int16_t* route_pos, const uint8_t* lane_ok,
+                                          int last_road, double px, double py, double heading, int lookahead,
+                                          int max_paths, int stride, int* n, double* x, double* y, double* h, double* w,
+                                          double* s, int* lane) {
+  MapDev m(*t);
+  m.route_pos = route_pos;
+  m.route_lane_ok = lane_ok;
+  MissionsDev ms{&last_road, nullptr};
+  const PathSeeds seed = compute_path_seeds(m, px, py, heading, 5.0, true, &ms, 0);
+  int knots[SMX_MAX_KNOTS];
+  int idx = 0;
+  if (seed.road < 0) return 0;
+  for (int li = 0; li < seed.n_lanes; ++li) {
+    const int st = seed_start(m, seed, li, px, py);
+    if (st < 0) continue;
+    BranchState bs;
+    bs.reset();
+    do {
+      if (idx < max_paths) {
+        const int p = idx;
+        n[p] = equally_spaced_path(m, seed.f, bs, st, lookahead, px, py, knots, 1, stride,
+                                   [&](int i, const WaypointOut& o) {
+                                     x[p * stride + i] = o.x;
+                                     y[p * stride + i] = o.y;
+                                     h[p * stride + i] = o.heading;
+                                     w[p * stride + i] = o.width;
+                                     s[p * stride + i] = o.speed;
+                                     lane[p * stride + i] = o.lane;
+                                   });
+      }
+      ++idx;
+    } while (bs.advance());
+  }
+  return idx;
+}

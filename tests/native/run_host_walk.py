@@ -18,6 +18,8 @@ lib = C.CDLL(sys.argv[1])
 dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
 lib.host_waypoint_paths.argtypes = [C.POINTER(nat.SmxMapTables), C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                     ip, dp, dp, dp, dp, dp, ip]
+lib.host_routed_waypoint_paths.argtypes = [C.POINTER(nat.SmxMapTables), C.POINTER(C.c_int16), C.POINTER(C.c_uint8), C.c_int, C.c_double,
+                                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, ip, dp, dp, dp, dp, dp, ip]
 lib.host_nearest_lane.argtypes = [C.POINTER(nat.SmxMapTables), C.c_double, C.c_double, C.c_double, dp, ip]
 out = {}
 for name in sys.argv[2:]:
@@ -51,6 +53,47 @@ for name in sys.argv[2:]:
             if not ok:
                 bad.append(i)
         out[f"waypoints_{name}_{lookahead}"] = dict(differing=bad, worst=worst, poses=len(w["poses"]))
+    # ---- fixed routes (missions_<map>.npz): smx_set_missions' per-slot tables, built here by the same rule
+    g = np.load(os.path.join(golden, f"missions_{name}.npz"))
+    lane_no = np.array([cm.lane_ids.index(str(l)) for l in g["lane_ids"]])
+    off = g["route_off"]
+    w = {k[len("wp32_"):]: g[k] for k in g.files if k.startswith("wp32_")}
+    bad, worst = [], 0.0
+    for r in range(int(g["n_routes"])):
+        roads = [cm.road_ids.index(str(x)) for x in g["route_roads"][off[r]:off[r + 1]]]
+        pos = np.full(len(cm.road_ids), -1, np.int16)
+        for i_, rd in enumerate(roads):
+            if pos[rd] < 0:
+                pos[rd] = i_
+        ok_lane = np.zeros(len(cm.lane_ids), np.uint8)
+        for ln_ in range(len(cm.lane_ids)):
+            rd = cm.lane_road[ln_]
+            good = pos[rd] >= 0
+            if good and rd != roads[-1]:
+                good = any(pos[cm.lane_road[o_]] >= 0 for o_ in cm.lane_out_idx[cm.lane_out_off[ln_]:cm.lane_out_off[ln_ + 1]])
+            ok_lane[ln_] = 1 if good else 0
+        for i in np.flatnonzero(g["pose_route"] == r):
+            px, py, ph = g["poses"][i]
+            cnt = lib.host_routed_waypoint_paths(C.byref(tables), pos.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                 ok_lane.ctypes.data_as(C.POINTER(C.c_uint8)), int(roads[-1]), px, py, ph, 32, MAXP, ST,
+                                                 n.ctypes.data_as(ip), *(a.ctypes.data_as(dp) for a in (x, y, h, wd, sp)),
+                                                 ln.ctypes.data_as(ip))
+            p0, p1 = w["path_off"][i], w["path_off"][i + 1]
+            ok = cnt == p1 - p0
+            for k in range(min(cnt, p1 - p0, MAXP)):
+                a, b = w["wp_off"][p0 + k], w["wp_off"][p0 + k + 1]
+                ok = ok and n[k] == b - a
+                if not ok:
+                    break
+                sl, me = slice(a, b), slice(k * ST, k * ST + b - a)
+                ok = ok and np.array_equal(ln[me], lane_no[w["lane"][sl]])
+                err = max(np.abs(x[me] - w["x"][sl]).max(), np.abs(y[me] - w["y"][sl]).max(), np.abs(h[me] - w["heading"][sl]).max(),
+                          np.abs(wd[me] - w["width"][sl]).max(), np.abs(sp[me] - w["speed"][sl]).max())
+                worst = max(worst, float(err))
+                ok = ok and err <= 1e-9
+            if not ok:
+                bad.append(int(i))
+    out[f"routed_{name}"] = dict(differing=bad, worst=worst, poses=len(g["poses"]))
     g = np.load(os.path.join(golden, f"nearest_{name}.npz"))
     lane_no = np.array([cm.lane_ids.index(str(l)) for l in g["lane_ids"]] + [-1])
     bad = []

@@ -182,7 +182,7 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
 class OracleBatch:
     """E independent oracle envs driven with the same spawns/actions as the device."""
 
-    def __init__(self, net, cm, cfg, spawns_ep0, social_ep0=None, vias=None):
+    def __init__(self, net, cm, cfg, spawns_ep0, social_ep0=None, vias=None, missions=None):
         self.cfg = cfg
         self.road_map = ORoadNetwork(net, lanepoint_spacing=cm.lanepoint_spacing)
         self.lane_no = {lid: i for i, lid in enumerate(cm.lane_ids)}
@@ -199,9 +199,13 @@ class OracleBatch:
             if vias is not None:
                 ovias = [[dict(lane_id=v.lane_id, position=v.position, hit_distance=v.hit_distance,
                                required_speed=v.required_speed) for v in lst] for lst in vias[:self.N - K]]
+            omissions = None
+            if missions is not None:  # smarts_amd.missions.PlannedMission | None per slot
+                omissions = [dict(route=list(m.route_roads), goal=tuple(m.goal)) if m is not None else None
+                             for m in missions[:self.N - K]]
             self.envs.append(OracleEnv(self.road_map, spawns_ep0[rows], [ocfg] * (self.N - K), dt=cfg.dt, social=social,
                                        social_speed_factor=cfg.social_speed_factor, vias=ovias,
-                                       social_model=cfg.social_model))
+                                       social_model=cfg.social_model, missions=omissions))
 
     def _stack(self, parts):
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}

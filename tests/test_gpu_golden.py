@@ -45,28 +45,15 @@ def _sim_at_poses(cm, poses, speeds=None, **cfg_kw):
     return BatchedSim(cm, cfg, spawns=spawns)
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
-@pytest.mark.parametrize("name", MAP_NAMES)
-def test_waypoint_rows_equal_the_reference(name, strategy, compiled_maps):
-    cm = compiled_maps(name)
-    w = np.load(os.path.join(GOLDEN, f"waypoints_{name}_empty_route_32.npz"))
-    lane_no = np.array([cm.lane_ids.index(str(l)) for l in w["lane_ids"]])  # golden lane number -> table index
-    P, W = 8, 33  # every waypoint of every path the rows can hold
-    sim = _sim_at_poses(cm, w["poses"], wp_paths=P, wp_len=W, wp_lookahead=32, launch_strategy=strategy)
-    out = sim.reset()
-    if strategy == "large":
-        # the reset pass is one form for every batch; the large form's waypoint kernels run in a tick: stand still
-        # (zero speed, no action moves a stationary sedan's centre) and read the tick's rows
-        import torch
-
-        out = sim.step(torch.full((len(w["poses"]), 1), -1, dtype=torch.int8, device="cuda"))
+def differing_waypoint_rows(out, w, lane_no, P, W):
+    """Indices of the golden poses whose waypoint rows (vehicle 0 of env i) differ from the flattened reference
+    paths `w` (path_off, wp_off, x, y, heading, lane, lane_index, width, speed)."""
     cnt = _host(out["wp_count"])[:, 0]
     pos, hd = _host(out["wp_pos"])[:, 0], _host(out["wp_heading"])[:, 0]
     wd, sp = _host(out["wp_lane_width"])[:, 0], _host(out["wp_speed_limit"])[:, 0]
     lid, lidx = _host(out["wp_lane_id"])[:, 0], _host(out["wp_lane_index"])[:, 0]
-    sim.close()
     differing = []
-    for i in range(len(w["poses"])):
+    for i in range(len(w["path_off"]) - 1):
         p0, p1 = w["path_off"][i], w["path_off"][i + 1]
         ok = cnt[i, 0] == min(p1 - p0, 255)
         for k in range(min(p1 - p0, P)):
@@ -87,6 +74,26 @@ def test_waypoint_rows_equal_the_reference(name, strategy, compiled_maps):
             ok = ok and cnt[i, 1 + k] == 0 and not pos[i, k].any()
         if not ok:
             differing.append(i)
+    return differing
+
+
+@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("name", MAP_NAMES)
+def test_waypoint_rows_equal_the_reference(name, strategy, compiled_maps):
+    cm = compiled_maps(name)
+    w = np.load(os.path.join(GOLDEN, f"waypoints_{name}_empty_route_32.npz"))
+    lane_no = np.array([cm.lane_ids.index(str(l)) for l in w["lane_ids"]])  # golden lane number -> table index
+    P, W = 8, 33  # every waypoint of every path the rows can hold
+    sim = _sim_at_poses(cm, w["poses"], wp_paths=P, wp_len=W, wp_lookahead=32, launch_strategy=strategy)
+    out = sim.reset()
+    if strategy == "large":
+        # the reset pass is one form for every batch; the large form's waypoint kernels run in a tick: stand still
+        # (zero speed, no action moves a stationary sedan's centre) and read the tick's rows
+        import torch
+
+        out = sim.step(torch.full((len(w["poses"]), 1), -1, dtype=torch.int8, device="cuda"))
+    differing = differing_waypoint_rows(out, w, lane_no, P, W)
+    sim.close()
     assert differing == tie_sensitive.WAYPOINTS[(name, "empty_route", 32)], differing
 
 

@@ -54,3 +54,6 @@ def test_device_walk_source_under_sanitizers_matches_the_reference(form, tmp_pat
             r = res[f"waypoints_{name}_{lookahead}"]
             assert r["differing"] == tie_sensitive.WAYPOINTS[(name, "empty_route", lookahead)], (name, lookahead, r)
         assert res[f"nearest_{name}"]["differing"] == [], name
+        # fixed routes (missions_<map>.npz): seeds along the route + the per-lane route table
+        r = res[f"routed_{name}"]
+        assert r["differing"] == tie_sensitive.ROUTE_WAYPOINTS[(name, 32)] and r["poses"] > 100, (name, r)
