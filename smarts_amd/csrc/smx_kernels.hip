@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_social(const KernelArgs a) {
 //          (sumo_road_network.py:815-882), used by the waypoints role now and by k_control next tick
 // =================================================================================
 // one half of k_scan for one vehicle team (see k_scan)
-template <int TEAM>
+template <int TEAM, bool ROUTED>
 __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, const smx_config& c, size_t gid,
                                           size_t total, int rank, int flags, int role) {
   SMX_TSTAMP(ts0);
@@ -1043,13 +1043,13 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   }
   SMX_TSTAMP(ts4b);
   SMX_TACC(9, ts4, ts4b);
-  const PathSeeds seed = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, 5.0, true, t, sc, a.missions, (int)(gid % (size_t)c.num_vehicles));
+  const PathSeeds seed = team_compute_path_seeds<TEAM, ROUTED>(m, s.x, s.y, s.heading, 5.0, true, t, sc, a.missions, (int)(gid % (size_t)c.num_vehicles));
   // without the waypoints sensor the observation still takes the first waypoint of
   // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
   // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
   int obs_start = -1, trip_start = -1;
   if (!wp_on || (flags & SMX_F_FIRST)) {
-    const PathSeeds ts = team_compute_path_seeds<TEAM>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc, a.missions, 0);
+    const PathSeeds ts = team_compute_path_seeds<TEAM, false>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc, a.missions, 0);
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }
@@ -1072,7 +1072,8 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
 #ifndef SMX_SCAN_WAVES
 #define SMX_SCAN_WAVES 3
 #endif
-template <bool SPLIT>
+// ROUTED: the instance that knows fixed routes (smx_set_missions); batches without missions run the other one
+template <bool SPLIT, bool ROUTED = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8))) __launch_bounds__(SMX_BLOCK) k_scan(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
@@ -1088,19 +1089,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
   if (SPLIT) {
     if (blockIdx.x & 1)
-      scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 1);
+      scan_role<SMX_TEAM, ROUTED>(a, m, c, gid, total, rank, flags, 1);
     else
-      scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 0);
+      scan_role<SMX_TEAM, ROUTED>(a, m, c, gid, total, rank, flags, 0);
   } else {
-    scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 0);
-    scan_role<SMX_TEAM>(a, m, c, gid, total, rank, flags, 1);
+    scan_role<SMX_TEAM, ROUTED>(a, m, c, gid, total, rank, flags, 0);
+    scan_role<SMX_TEAM, ROUTED>(a, m, c, gid, total, rank, flags, 1);
   }
 }
 
 // One half of the scan as a launch of its own (large batches): the road facts feed the observe role only and
 // the path seeds the waypoint kernels only, so the two go to different streams and each keeps the registers
 // it needs (the facts half alone fits more wavefronts per SIMD than the pair).
-template <int ROLE>
+template <int ROLE, bool ROUTED = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_half(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -1109,7 +1110,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __lau
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
-  scan_role<SMX_TEAM_LARGE>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
+  scan_role<SMX_TEAM_LARGE, ROUTED>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
 }
 
 // =================================================================================
@@ -2962,7 +2963,7 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
       if (pr < pairs) {
         const size_t gid = g0 + (pr >> 1);
         const int flags = a.st.flags[gid];
-        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role<SMX_TEAM>(a, m, c, gid, total, team_rank<SMX_TEAM>(), flags, (int)(pr & 1));
+        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role<SMX_TEAM, true>(a, m, c, gid, total, team_rank<SMX_TEAM>(), flags, (int)(pr & 1));
       }
     }
   }
@@ -3758,6 +3759,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     else
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, st_, k);
   };
+  const bool routed = h->missions.route_last != nullptr;  // some slot has a fixed route: the scan instance that knows them
   auto observation_pass = [&](const KernelArgs& k, bool phases) {
     // Large batches, no per-kernel timing asked: the grid maps and the lidar (which read poses only) leave on
     // side stream 0 at once and overlap the scan — kernels bound by their own write stream beside one bound by
@@ -3779,12 +3781,21 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       // caller's, road facts (-> observe) on side 1
       if (fork) (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
       const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
-      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
-      hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
+      if (routed)
+        hipLaunchKernelGGL((k_scan_half<1, true>), dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      else
+        hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
     } else if (scan_split) {
-      hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      if (routed)
+        hipLaunchKernelGGL((k_scan<true, true>), dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      else
+        hipLaunchKernelGGL(k_scan<true>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     } else {
-      hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      if (routed)
+        hipLaunchKernelGGL((k_scan<false, true>), dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      else
+        hipLaunchKernelGGL(k_scan<false>, dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
     }
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SCAN + 1], stream);
     if (!fork) {

@@ -380,8 +380,9 @@ __device__ inline int team_closest_on_route(const MapDev& m, const RouteFilter& 
   return all.idx == 0x7fffffff ? -1 : all.idx;
 }
 
-// compute_path_seeds, team form (see smx_roadmap.h for the semantics)
-template <int TEAM>
+// compute_path_seeds, team form (see smx_roadmap.h for the semantics).  ROUTED: some slot has a fixed route
+// (the instance without that code serves every batch until smx_set_missions is called).
+template <int TEAM, bool ROUTED>
 __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
                                                     double within_radius, bool has_route_object, const Top10& t,
                                                     const Top10Scores& sc, const MissionsDev& ms, int slot) {
@@ -393,7 +394,7 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
   for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
   bool routed = false;
   SMX_TSTAMP(tp0);
-  if (has_route_object && s.f.fixed_route(ms, slot, m.n_roads)) {
+  if (ROUTED && has_route_object && s.f.fixed_route(ms, slot, m.n_roads)) {
     const int best = team_closest_on_route<TEAM>(m, s.f, px, py);
     s.road = best >= 0 ? m.lane_road[m.lp_rec[best].lane] : -1;
     routed = true;
