@@ -216,6 +216,11 @@ typedef struct smx_map_tables {
   const int32_t* sg_off;         /* sg_nx * sg_ny + 1 */
   const smx_seg_rec* sg_rec;
   double default_lane_width;     /* sumo_road_network.py:80 */
+  /* RoadWaypointsSensor's neighbourhood (sensors.py:991-1040) */
+  const int32_t* lane_in_off;    /* n_lanes + 1 */
+  const int32_t* lane_in_idx;    /* Lane.incoming_lanes (sumo_road_network.py:342-348), sumolib's order */
+  const int32_t* road_par_off;   /* n_roads + 1 */
+  const int32_t* road_par_idx;   /* Road.parallel_roads (sumo_road_network.py:607-618) */
 } smx_map_tables;
 
 /* ---- simulation state, caller-owned device memory, struct-of-arrays over (E, N) ---- */

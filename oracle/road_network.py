@@ -146,6 +146,27 @@ class ORoad:
     def outgoing_roads(self):
         return [self._map.road_by_id(e.getID()) for e in self._se.getOutgoing().keys()]
 
+    @property
+    def parallel_roads(self):
+        """sumo_road_network.py:607-618 (a junction-internal edge has no from / to node in sumolib: the
+        reference cannot be asked there; [] here)."""
+        from_node, to_node = self._se.getFromNode(), self._se.getToNode()
+        if from_node is None or to_node is None:
+            return []
+        return [
+            self._map.road_by_id(edge.getID())
+            for edge in from_node.getOutgoing()
+            if self.road_id != edge.getID() and edge.getToNode().getID() == to_node.getID()
+        ]
+
+    def oncoming_roads_at_point(self, point):
+        """sumo_road_network.py:596-605."""
+        result = []
+        for lane in self.lanes:
+            offset = lane.to_lane_coord(point)[0]
+            result += [ol.road for ol in lane.oncoming_lanes_at_offset(offset) if ol.road is not self]
+        return result
+
 
 class LP:
     """LinkedLanePoint + LanePoint flattened (lanepoints.py:46-70)."""

@@ -162,3 +162,41 @@ def lidar(ego, others, rays, lidar_offset=(0.0, 0.0, 1.0)):
             hits[i] = True
             pts[i] = origin + best * d
     return pts, hits
+
+
+# ---------------------------------------------------------------------------------------------
+# RoadWaypointsSensor (sensors.py:991-1040)
+# ---------------------------------------------------------------------------------------------
+def road_waypoints(rmap, position, heading, horizon=32, route=None):
+    """``RoadWaypointsSensor.__call__`` -> ``{lane_id: [waypoint paths]}`` in the reference's insertion order
+    (the lanes of the nearest lane's road, of its parallel roads, of the roads oncoming at the point).
+    ``route``: the plan's road ids ([] / None = the endless mission's empty route: no filter)."""
+    lane = rmap.nearest_lane(position)
+    if not lane:
+        return {}
+    road = lane.road
+    point = (position[0], position[1], position[2] if len(position) > 2 else 0.0)
+    lane_paths = {}
+    for croad in [road] + road.parallel_roads + road.oncoming_roads_at_point(point):
+        for ln in croad.lanes:
+            lane_paths[ln.lane_id] = _paths_for_lane(rmap, ln, point, horizon, route, None)
+    return lane_paths
+
+
+def _paths_for_lane(rmap, lane, point, horizon, route, overflow_offset):
+    """sensors.py:1014-1040 (the waypoint spacing is assumed to be 1 m there too)."""
+    if overflow_offset is None:
+        offset = lane.offset_along_lane(point)
+        start_offset = offset - horizon
+    else:
+        start_offset = lane.length + overflow_offset
+    incoming_lanes = lane.incoming_lanes
+    if start_offset < 0 and len(incoming_lanes) > 0:
+        paths = []
+        for lane_in in incoming_lanes:
+            paths += _paths_for_lane(rmap, lane_in, point, horizon, route, start_offset)
+        return paths
+    start_offset = max(0, start_offset)
+    wp_start = lane.from_lane_coord(start_offset)
+    # Pose.from_center(wp_start, heading).as_position2d() -> the start point; lookahead = 2 x horizon
+    return rmap.lane_waypoint_paths_at(lane, wp_start[:2], horizon * 2, list(route) if route else None)

@@ -72,6 +72,7 @@ class SmxMapTables(C.Structure):
         ("lpg_off", _p), ("lpg_pts", _p),
         ("sg_x0", _f64), ("sg_y0", _f64), ("sg_cell", _f64), ("sg_nx", _i32), ("sg_ny", _i32),
         ("sg_off", _p), ("sg_rec", _p), ("default_lane_width", _f64),
+        ("lane_in_off", _p), ("lane_in_idx", _p), ("road_par_off", _p), ("road_par_idx", _p),
     ]
 
 

@@ -3292,6 +3292,12 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   }
   for (int i = 0; i < t->sg_off[sg_cells]; ++i)
     if (t->sg_rec[i].lane < 0 || t->sg_rec[i].lane >= t->n_lanes) return fail(h, SMX_ERR_INVALID, "segment record out of range");
+  if (!t->lane_in_off || !t->lane_in_idx || !t->road_par_off || !t->road_par_idx)
+    return fail(h, SMX_ERR_INVALID, "map tables: lane_in_* / road_par_* missing");
+  for (int i = 0; i < t->lane_in_off[nl]; ++i)
+    if (t->lane_in_idx[i] < 0 || t->lane_in_idx[i] >= t->n_lanes) return fail(h, SMX_ERR_INVALID, "incoming lane out of range");
+  for (int i = 0; i < t->road_par_off[nr]; ++i)
+    if (t->road_par_idx[i] < 0 || t->road_par_idx[i] >= t->n_roads) return fail(h, SMX_ERR_INVALID, "parallel road out of range");
   h->dagm_reach = 0.0;
   for (size_t i = 0; i < nl; ++i) h->dagm_reach = std::max(h->dagm_reach, 0.5 * t->lane_width[i]);
 #define ADD(field, count, type) size_t off_##field = w.add(t->field, (size_t)(count) * sizeof(type))
@@ -3307,6 +3313,10 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   ADD(shape_rec, nv, smx_shape_rec);
   ADD(lane_out_off, nl + 1, int32_t);
   ADD(lane_out_idx, t->lane_out_off[nl], int32_t);
+  ADD(lane_in_off, nl + 1, int32_t);
+  ADD(lane_in_idx, t->lane_in_off[nl], int32_t);
+  ADD(road_par_off, nr + 1, int32_t);
+  ADD(road_par_idx, t->road_par_off[nr], int32_t);
   ADD(road_lane_off, nr + 1, int32_t);
   ADD(road_lanes, t->road_lane_off[nr], int32_t);
   ADD(road_is_junction, nr, uint8_t);
@@ -3348,6 +3358,10 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   PTR(shape_rec, smx_shape_rec);
   PTR(lane_out_off, int32_t);
   PTR(lane_out_idx, int32_t);
+  PTR(lane_in_off, int32_t);
+  PTR(lane_in_idx, int32_t);
+  PTR(road_par_off, int32_t);
+  PTR(road_par_idx, int32_t);
   PTR(road_lane_off, int32_t);
   PTR(road_lanes, int32_t);
   PTR(road_is_junction, uint8_t);

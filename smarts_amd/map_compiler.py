@@ -75,12 +75,16 @@ class CompiledMap:
     shape_y: np.ndarray
     lane_out_off: np.ndarray
     lane_out_idx: np.ndarray
+    lane_in_off: np.ndarray   # Lane.incoming_lanes (sumo_road_network.py:342-348), in sumolib's order
+    lane_in_idx: np.ndarray
     # roads
     road_ids: List[str]
     road_lane_off: np.ndarray
     road_lanes: np.ndarray
     road_is_junction: np.ndarray
     road_out_road: np.ndarray
+    road_par_off: np.ndarray  # Road.parallel_roads (sumo_road_network.py:607-618)
+    road_par_idx: np.ndarray
     # lanepoints
     lp_x: np.ndarray
     lp_y: np.ndarray
@@ -288,6 +292,24 @@ def compile_map(net: SumoNet, lanepoint_spacing: float = 1.0, default_lane_width
     lane_out_off[1:] = np.cumsum([len(o) for o in out_lanes])
     lane_out_idx = np.array([j for o in out_lanes for j in o], dtype=np.int32)
 
+    in_lanes = [[lane_no[i.getID()] for i in l.getIncoming()] for l in lanes]
+    lane_in_off = np.zeros(len(lanes) + 1, dtype=np.int32)
+    lane_in_off[1:] = np.cumsum([len(i) for i in in_lanes])
+    lane_in_idx = np.array([j for i in in_lanes for j in i], dtype=np.int32)
+    # parallel roads: the other edges between the same two junctions (junction-internal edges carry no
+    # from / to node: sumolib leaves them None and Road.parallel_roads cannot be asked there — none here)
+    par = []
+    for e in edges:
+        fn, tn = e.getFromNode(), e.getToNode()
+        if fn is None or tn is None:
+            par.append([])
+            continue
+        par.append([road_no[o.getID()] for o in fn.getOutgoing()
+                    if o.getID() != e.getID() and o.getToNode() is not None and o.getToNode().getID() == tn.getID()])
+    road_par_off = np.zeros(len(edges) + 1, dtype=np.int32)
+    road_par_off[1:] = np.cumsum([len(q) for q in par])
+    road_par_idx = np.array([j for q in par for j in q], dtype=np.int32)
+
     shape_off = np.zeros(len(lanes) + 1, dtype=np.int32)
     shape_off[1:] = np.cumsum([len(l.shape) for l in lanes])
     shape_x = np.array([p[0] for l in lanes for p in l.shape], dtype=np.float64)
@@ -361,6 +383,10 @@ def compile_map(net: SumoNet, lanepoint_spacing: float = 1.0, default_lane_width
         shape_y=shape_y,
         lane_out_off=lane_out_off,
         lane_out_idx=lane_out_idx,
+        lane_in_off=lane_in_off,
+        lane_in_idx=lane_in_idx,
+        road_par_off=road_par_off,
+        road_par_idx=road_par_idx,
         road_ids=[e.getID() for e in edges],
         road_lane_off=road_lane_off,
         road_lanes=road_lanes,
@@ -496,6 +522,7 @@ _MAP_ARRAYS = [
     ("shape_x", np.float64), ("shape_y", np.float64), ("lane_out_off", np.int32), ("lane_out_idx", np.int32),
     ("road_lane_off", np.int32), ("road_lanes", np.int32), ("road_is_junction", np.uint8),
     ("road_out_road", np.int32), ("lpg_off", np.int32), ("sg_off", np.int32),
+    ("lane_in_off", np.int32), ("lane_in_idx", np.int32), ("road_par_off", np.int32), ("road_par_idx", np.int32),
 ]
 
 

@@ -195,8 +195,33 @@ class Edge:
     def getIncoming(self) -> Dict["Edge", List[Connection]]:
         return self.incoming
 
+    def getFromNode(self) -> Optional["Node"]:
+        """sumolib: the junction the edge leaves (None for junction-internal edges, which carry no from / to)."""
+        return self.net.node_objects.get(self.from_node) if self.from_node else None
+
+    def getToNode(self) -> Optional["Node"]:
+        return self.net.node_objects.get(self.to_node) if self.to_node else None
+
     def __hash__(self):
         return id(self)
+
+
+@dataclass(eq=False)
+class Node:
+    """``sumolib.net.node.Node``: id + the edges that leave / enter it, in the net file's edge order."""
+
+    node_id: str
+    outgoing: List[Edge] = field(default_factory=list)
+    incoming: List[Edge] = field(default_factory=list)
+
+    def getID(self) -> str:
+        return self.node_id
+
+    def getOutgoing(self) -> List[Edge]:
+        return self.outgoing
+
+    def getIncoming(self) -> List[Edge]:
+        return self.incoming
 
 
 class SumoNet:
@@ -207,6 +232,7 @@ class SumoNet:
         self.id2edge: Dict[str, Edge] = {}
         self.id2lane: Dict[str, Lane] = {}
         self.nodes: Dict[str, Point2] = {}
+        self.node_objects: Dict[str, Node] = {}
         self.conv_boundary: Tuple[float, float, float, float] = (0.0, 0.0, 0.0, 0.0)
         self.shifted_by: Tuple[float, float] = (0.0, 0.0)
         self.source: str = ""
@@ -417,6 +443,10 @@ def _build(desc: dict, shift_to_origin: bool) -> SumoNet:
             net.id2lane[lane.lane_id] = lane
         net.edges.append(e)
         net.id2edge[e.edge_id] = e
+        if e.from_node:
+            net.node_objects.setdefault(e.from_node, Node(e.from_node)).outgoing.append(e)
+        if e.to_node:
+            net.node_objects.setdefault(e.to_node, Node(e.to_node)).incoming.append(e)
     for cd in desc["connections"]:
         fe = net.id2edge.get(cd["from"])
         te = net.id2edge.get(cd["to"])

@@ -839,6 +839,81 @@ def dump_missions(rn, net, rng, name):
     return out
 
 
+def dump_road_waypoints(rn, net, rng, name):
+    """The reference's RoadWaypointsSensor (sensors.py:991-1040) on mock vehicle / sim / plan objects, with the
+    endless mission's empty route and with a fixed route.  Poses whose nearest lane is junction-internal make the
+    reference raise (Road.parallel_roads asks sumolib for the internal edge's from-node, which is None): they
+    are recorded as such."""
+    from unittest.mock import Mock
+
+    from smarts.core.coordinates import Heading, Pose
+    from smarts.core.sensors import RoadWaypointsSensor
+    from smarts.core.utils.math import fast_quaternion_from_angle
+
+    lane_ids = sorted(l.getID() for l in net.all_lanes())
+    lane_no = {lid: i for i, lid in enumerate(lane_ids)}
+    n = {"loop": 40, "4lane": 60, "minicity": 60}[name]
+    poses = sample_poses(net, rng, n, lateral=1.5, heading_noise=0.3, far_fraction=0.05)
+    # a fixed route for the second half of the poses: through the first reachable pair of roads
+    normal = net.getEdges(False)
+    route = None
+    for _ in range(200):
+        a, b = (normal[i] for i in rng.integers(len(normal), size=2))
+        r = rn.generate_routes(rn.road_by_id(a.getID()), rn.road_by_id(b.getID()))[0]
+        if len(r.roads) >= 3:
+            route = r
+            break
+    route_ids = [road.road_id for road in route.roads]
+    if name != "loop":
+        on_route = [l for l in net.all_lanes() if l.getEdge().getID() in route_ids and not l.getEdge().isSpecial()]
+
+        class _LaneSet:
+            def all_lanes(self):
+                return on_route
+
+        poses[n // 2:] = sample_poses(_LaneSet(), rng, n - n // 2, lateral=1.5, heading_noise=0.3, far_fraction=0.0)
+    rec = dict(lane_off=[0], lane=[], path_off=[0], wp_off=[0], x=[], y=[], heading=[], wp_lane=[], lane_index=[], width=[], speed=[])
+    raised, routed = [], []
+    for i, (x, y, h) in enumerate(poses):
+        hd = Heading(h)
+        pose = Pose(position=np.array([x, y, 0.0]), orientation=fast_quaternion_from_angle(hd), heading_=hd)
+        vehicle = Mock()
+        vehicle.pose = pose
+        vehicle.position = pose.position
+        vehicle.heading = hd
+        sim = Mock()
+        sim.road_map = rn
+        plan = Mock()
+        use_route = i >= n // 2
+        plan.route = route if use_route else rn.empty_route()
+        routed.append(1 if use_route else 0)
+        sensor = RoadWaypointsSensor(vehicle, sim, plan, horizon=32)
+        try:
+            lanes = sensor().lanes
+            raised.append(0)
+        except AttributeError:
+            lanes = {}
+            raised.append(1)
+        for lane_id, paths in lanes.items():
+            rec["lane"].append(lane_no[lane_id])
+            for p_ in paths:
+                for wp in p_:
+                    rec["x"].append(float(wp.pos[0]))
+                    rec["y"].append(float(wp.pos[1]))
+                    rec["heading"].append(float(wp.heading))
+                    rec["wp_lane"].append(lane_no[wp.lane_id])
+                    rec["lane_index"].append(int(wp.lane_index))
+                    rec["width"].append(float(wp.lane_width))
+                    rec["speed"].append(float(wp.speed_limit))
+                rec["wp_off"].append(len(rec["x"]))
+            rec["path_off"].append(len(rec["wp_off"]) - 1)
+        rec["lane_off"].append(len(rec["lane"]))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(lane_ids=np.array(lane_ids), poses=np.array(poses), raised=np.array(raised, dtype=np.uint8),
+               routed=np.array(routed, dtype=np.uint8), route_roads=np.array(route_ids), horizon=np.array(32))
+    return out
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -869,7 +944,14 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"missions_{name}.npz"), **ms)
             print(name, "missions: routes", int(ms["n_routes"]), "poses", len(ms["poses"]), "off-route",
                   int(ms["off_route"].sum()), "wrong-way", int(ms["wrong_way"].sum()))
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias", "missions"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "roadwp"):
+        for name, rel in SCENARIOS.items():
+            net = load_net(os.path.join(REF, rel))
+            rw = dump_road_waypoints(make_reference_road_network(net), net, np.random.default_rng(5200 + len(name)), name)
+            np.savez_compressed(os.path.join(OUT, f"road_waypoints_{name}.npz"), **rw)
+            print(name, "road waypoints: poses", len(rw["poses"]), "lanes", len(rw["lane"]), "paths", len(rw["wp_off"]) - 1,
+                  "raised", int(rw["raised"].sum()))
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias", "missions", "roadwp"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

@@ -108,3 +108,56 @@ def test_positional_goal_matches_reference():
     got = [(x - gx) ** 2 + (y - gy) ** 2 <= gr ** 2 for x, y in g["goal_probes"]]
     assert np.array_equal(np.array(got, dtype=np.uint8), g["goal_reached"])
     assert 0 < g["goal_reached"].sum() < len(got)
+
+
+# ---------------------------------------------------------------------------------------------
+# RoadWaypointsSensor (sensors.py:991-1040): tests/golden/road_waypoints_<map>.npz
+# ---------------------------------------------------------------------------------------------
+def road_waypoints_equal(got, g, i, lane_ids):
+    """`got` ({lane id: [paths]}) against pose i of the flattened fixture -> (equal, worst |error|)."""
+    l0, l1 = g["lane_off"][i], g["lane_off"][i + 1]
+    if [lane_ids.index(k) for k in got] != list(g["lane"][l0:l1]):
+        return False, 0.0
+    worst = 0.0
+    for j, paths in enumerate(got.values()):
+        p0, p1 = g["path_off"][l0 + j], g["path_off"][l0 + j + 1]
+        if len(paths) != p1 - p0:
+            return False, 0.0
+        for k, p in enumerate(paths):
+            a, b = g["wp_off"][p0 + k], g["wp_off"][p0 + k + 1]
+            if len(p) != b - a or [lane_ids.index(w.lane_id) for w in p] != list(g["wp_lane"][a:b]):
+                return False, 0.0
+            if [w.lane_index for w in p] != list(g["lane_index"][a:b]):
+                return False, 0.0
+            for key, vals in (("x", [w.pos[0] for w in p]), ("y", [w.pos[1] for w in p]), ("heading", [w.heading for w in p]),
+                              ("width", [w.lane_width for w in p]), ("speed", [w.speed_limit for w in p])):
+                worst = max(worst, float(np.abs(np.array(vals, dtype=np.float64) - g[key][a:b]).max()))
+    return True, worst
+
+
+@pytest.mark.parametrize("name", MAP_NAMES)
+def test_road_waypoints_match_reference(name, oracle_maps):
+    import tie_sensitive
+    from oracle.sensors_extra import road_waypoints
+
+    om = oracle_maps(name)
+    g = np.load(os.path.join(GOLDEN, f"road_waypoints_{name}.npz"))
+    lane_ids = [str(x) for x in g["lane_ids"]]
+    route = [str(r) for r in g["route_roads"]]
+    answered, tie_sensitive_poses = 0, []
+    for i, (x, y, h) in enumerate(g["poses"]):
+        if g["raised"][i]:
+            continue  # nearest lane junction-internal: the reference raises (no from-node in sumolib)
+        rt = route if g["routed"][i] else None
+        OLanePoints.tie_rule = "kdtree"
+        try:
+            ok, err = road_waypoints_equal(road_waypoints(om, (x, y, 0.0), h, 32, rt), g, i, lane_ids)
+        finally:
+            OLanePoints.tie_rule = "index"
+        assert ok and err == 0.0, f"pose {i}: oracle (kdtree ties) != reference"
+        ok2, err2 = road_waypoints_equal(road_waypoints(om, (x, y, 0.0), h, 32, rt), g, i, lane_ids)
+        if not (ok2 and err2 == 0.0):
+            tie_sensitive_poses.append(i)
+        answered += 1
+    assert answered >= 25 and g["routed"].sum() > 0
+    assert tie_sensitive_poses == tie_sensitive.ROAD_WAYPOINTS[name], tie_sensitive_poses

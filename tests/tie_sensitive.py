@@ -26,5 +26,8 @@ ROUTE_WAYPOINTS = {
     ("minicity", 16): [], ("minicity", 32): [],
 }
 
+# road_waypoints_<map>.npz: pose indices
+ROAD_WAYPOINTS = {"loop": [], "4lane": [], "minicity": []}
+
 # controller_<map>.npz: row indices (the controller asks waypoint_paths with lookahead 16 at the vehicle pose)
 CONTROLLER = {"loop": [], "4lane": [179], "minicity": []}
