@@ -79,7 +79,8 @@ enum {
   SMX_SENSOR_ACCELEROMETER = 1 << 2,
   SMX_SENSOR_OGM = 1 << 3,
   SMX_SENSOR_LIDAR = 1 << 4,
-  SMX_SENSOR_DAGM = 1 << 5   /* drivable-area grid map (sensors.py:675-716) */
+  SMX_SENSOR_DAGM = 1 << 5,  /* drivable-area grid map (sensors.py:675-716) */
+  SMX_SENSOR_ROAD_WAYPOINTS = 1 << 6 /* RoadWaypointsSensor (sensors.py:991-1040) */
 };
 
 enum { SMX_SOCIAL_CONSTANT = 0, SMX_SOCIAL_IDM = 1 };
@@ -151,8 +152,17 @@ typedef struct smx_config {
    * than 1.6 m to its side, read at the start of the tick; gap = centre distance - 3.68.  Parity with
    * SUMO's own car-following is unpinned. */
   int32_t social_model;
-  int32_t pad_social;
+  /* RoadWaypointsSensor (agent_interface.py RoadWaypoints.horizon, sensors.py:991-1040): per lane of the nearest
+   * lane's road, its parallel roads and the roads oncoming at the vehicle, the waypoint paths of lookahead
+   * 2 x horizon that start `horizon` metres behind the vehicle (through incoming lanes where the lane is shorter).
+   * Dense rows: the first rw_lanes lanes (<= SMX_RW_LANE_CAP) in the reference's order, the first rw_paths paths
+   * of each, 2 x horizon + 1 waypoints per path; true counts are reported beside them. */
+  int32_t rw_horizon;        /* 1 .. SMX_RW_HORIZON_MAX; read when SMX_SENSOR_ROAD_WAYPOINTS is set */
+  int32_t rw_lanes;
+  int32_t rw_paths;
 } smx_config;
+#define SMX_RW_LANE_CAP 8
+#define SMX_RW_HORIZON_MAX 64
 
 /* ---- packed map records (smarts_amd.map_compiler.pack_tables) ---- */
 typedef struct smx_lp_rec {   /* one lanepoint = one 64-byte line (LanePoint + LinkedLanePoint, lanepoints.py:46-70) */
@@ -318,6 +328,8 @@ enum { /* indices into smx_outputs.count / .dtype: the pointers in declaration o
   SMX_OUT_WP_LANE_ID, SMX_OUT_WP_COUNT, SMX_OUT_NB_POS, SMX_OUT_NB_BOX, SMX_OUT_NB_HEADING, SMX_OUT_NB_SPEED,
   SMX_OUT_NB_LANE_INDEX, SMX_OUT_NB_LANE_ID, SMX_OUT_NB_SLOT, SMX_OUT_NB_COUNT, SMX_OUT_OGM, SMX_OUT_LIDAR_HIT,
   SMX_OUT_LIDAR_POINT, SMX_OUT_DAGM, SMX_OUT_COLLIDEES,
+  SMX_OUT_RW_LANE_COUNT, SMX_OUT_RW_LANE, SMX_OUT_RW_PATH_COUNT, SMX_OUT_RW_COUNT, SMX_OUT_RW_POS, SMX_OUT_RW_HEADING,
+  SMX_OUT_RW_LANE_WIDTH, SMX_OUT_RW_SPEED_LIMIT, SMX_OUT_RW_LANE_INDEX, SMX_OUT_RW_LANE_ID,
   SMX_OUT_BUFFERS
 };
 typedef struct smx_outputs {
@@ -367,10 +379,22 @@ typedef struct smx_outputs {
   /* collisions (smarts.py:1270-1291, sensors.py:206-211): bit j = the agent's chassis touches the vehicle in
    * slot j of its env this tick — one Collision(collidee_id) per set bit; events[SMX_EV_COLLISIONS] = any bit */
   uint64_t* collidees;   /* [E*N]                                             */
+  /* road waypoints (RoadWaypoints.lanes, sensors.py:999-1012), NULL if unused; L = rw_lanes, P = rw_paths,
+   * R = 2 * rw_horizon + 1.  Rows beyond a count are not written. */
+  uint8_t* rw_lane_count;   /* [E*N]          lanes the sensor reports (may exceed L)              */
+  int16_t* rw_lane;         /* [E*N][L]       their lane ids in the reference's dict order, -1 none */
+  int16_t* rw_path_count;   /* [E*N][L]       paths of that lane (may exceed P; saturates at 32767)  */
+  uint8_t* rw_count;        /* [E*N][L][P]    waypoints of the kept path (0 = no such path)         */
+  double* rw_pos;           /* [E*N][L][P][R][3]                                                    */
+  float* rw_heading;        /* [E*N][L][P][R]                                                       */
+  float* rw_lane_width;
+  float* rw_speed_limit;
+  int8_t* rw_lane_index;
+  int16_t* rw_lane_id;
   /* what the caller allocated: element count and SMX_DT_* of each buffer above, in declaration order
    * (SMX_OUT_*); 0 / SMX_DT_NONE for a NULL pointer */
   uint64_t count[SMX_OUT_BUFFERS];
-  uint8_t dtype[SMX_OUT_BUFFERS + 7]; /* (+7: keeps the struct a multiple of 8 bytes) */
+  uint8_t dtype[(SMX_OUT_BUFFERS + 7) & ~7]; /* (rounded up: keeps the struct a multiple of 8 bytes) */
 } smx_outputs;
 
 /* ---- entry points ---- */

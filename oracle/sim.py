@@ -57,6 +57,7 @@ class AgentConfig:
     ogm: Optional[tuple] = None  # (width, height, resolution) — OGM (agent_interface.py:42-51)
     dagm: Optional[tuple] = None  # (width, height, resolution) — DrivableAreaGridMap (agent_interface.py:29-38)
     lidar_rays: Optional[np.ndarray] = None  # base rays [R, 3] (sensors_extra.base_rays)
+    road_waypoints_horizon: Optional[int] = None  # RoadWaypoints.horizon (agent_interface.py); None = sensor off
 
 
 class _Agent:
@@ -440,6 +441,8 @@ class OracleEnv:
             o["ogm"] = sx.ogm(b, [ob for _, ob in alive_states], *cfg.ogm)
         if cfg.dagm is not None:  # sensors.py:307-312
             o["dagm"] = sx.dagm(b, rmap.lane_bands(), *cfg.dagm)
+        if cfg.road_waypoints_horizon is not None:  # sensors.py:277-281, 991-1040
+            o["road_waypoints"] = sx.road_waypoints(rmap, b.position, b.heading, cfg.road_waypoints_horizon, ag.route)
         if cfg.lidar_rays is not None:  # sensors.py:297-301
             o["lidar"] = sx.lidar(b, [ob for j, ob in alive_states if j != i], cfg.lidar_rays)
         if self.vias[i]:

@@ -27,6 +27,7 @@ TRAJ_COLS = 11
 SOCIAL_MODELS = {"constant": 0, "idm": 1}
 PHASES = ["control", "scan", "ogm", "sensors", "commit", "reset"]
 SENSOR_WAYPOINTS, SENSOR_NEIGHBORS, SENSOR_ACCELEROMETER, SENSOR_OGM, SENSOR_LIDAR, SENSOR_DAGM = 1, 2, 4, 8, 16, 32
+SENSOR_ROAD_WAYPOINTS = 64
 STATE_FIELDS = ["X", "Y", "HEADING", "U", "V", "R", "DELTA", "LAT_INT", "SPD_INT", "STEER", "THROTTLE", "SPD_ERR",
                 "MCL_X", "MCL_Y", "TRIP_X", "TRIP_Y", "TRIP_H", "DIST", "LV0_LONG", "LV0_LAT", "AV0_Z", "LV1_LONG",
                 "LV1_LAT", "AV1_Z", "PATH_SUM", "PREV_X", "PREV_Y"]
@@ -56,7 +57,7 @@ class SmxConfig(C.Structure):
         ("alive_min_ego", _i32), ("alive_min_total", _i32), ("alive_lists", _i32), ("alive_list_min", _i32 * 4),
         ("alive_list_mask", C.c_uint64 * 4),
         ("dagm_width", _i32), ("dagm_height", _i32), ("dagm_resolution", _f64),
-        ("social_model", _i32), ("pad_social", _i32),
+        ("social_model", _i32), ("rw_horizon", _i32), ("rw_lanes", _i32), ("rw_paths", _i32),
     ]
 
 
@@ -104,6 +105,8 @@ OUTPUT_FIELDS = [
     "wp_pos", "wp_heading", "wp_lane_width", "wp_speed_limit", "wp_lane_index", "wp_lane_id", "wp_count",
     "nb_pos", "nb_box", "nb_heading", "nb_speed", "nb_lane_index", "nb_lane_id", "nb_slot", "nb_count",
     "ogm", "lidar_hit", "lidar_point", "dagm", "collidees",
+    "rw_lane_count", "rw_lane", "rw_path_count", "rw_count", "rw_pos", "rw_heading", "rw_lane_width", "rw_speed_limit",
+    "rw_lane_index", "rw_lane_id",
 ]
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("learner"), "via_hit")
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_hit"), "via_near_count")
@@ -112,7 +115,7 @@ OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_near_count"), "via_near")
 
 class SmxOutputs(C.Structure):
     _fields_ = [(name, _p) for name in OUTPUT_FIELDS] + [
-        ("count", C.c_uint64 * len(OUTPUT_FIELDS)), ("dtype", C.c_uint8 * (len(OUTPUT_FIELDS) + 7))]
+        ("count", C.c_uint64 * len(OUTPUT_FIELDS)), ("dtype", C.c_uint8 * ((len(OUTPUT_FIELDS) + 7) & ~7))]
 
 
 def torch_dtype_code(t) -> int:

@@ -2991,6 +2991,139 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
 // in spills than it won: +20 % on loop 4096 x 32) and OGM tiles too large to ride along as dynamic LDS of every k_sensors workgroup
 __global__ void __launch_bounds__(SMX_BLOCK) k_ogm(const KernelArgs a) { ogm_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_dagm(const KernelArgs a) { dagm_role(a, (int)blockIdx.x); }
+// =================================================================================
+// k_road_waypoints: RoadWaypointsSensor (sensors.py:991-1040).  SMX_RW_LANE_CAP lanes of a wavefront share a
+// vehicle: every lane of the team builds the sensor's lane list for itself (the same serial steps, so the
+// team does not diverge), then team lane l follows road lane l: start `horizon` metres behind the vehicle
+// along the lane (through its incoming lanes, depth first in their order, where the lane is shorter), and from
+// each start every lanepoint path of lookahead 2 x horizon, interpolated like the waypoints sensor's
+// (equally_spaced_path, its knots in private memory: up to 2 x horizon + 2 of them).  An optional sensor off
+// the headline configurations: written for parity, not for throughput.
+// Where the reference cannot answer — the nearest lane is junction-internal: Road.parallel_roads asks sumolib
+// for the internal edge's from-node, which is None, and raises — the road has no parallel roads here.
+// =================================================================================
+#define SMX_RW_MAX_KNOTS (2 * SMX_RW_HORIZON_MAX + 4)
+#define SMX_RW_STACK 24
+struct RwLanes {
+  int n;  // lanes the sensor reports (the list keeps the first SMX_RW_LANE_CAP)
+  int lane[SMX_RW_LANE_CAP];
+  // lane_paths[lane.lane_id] = ...: a lane met again keeps its first place in the dict
+  __device__ __forceinline__ void add_road(const MapDev& m, int road) {
+    for (int k = m.road_lane_off[road]; k < m.road_lane_off[road + 1]; ++k) {
+      const int ln = m.road_lanes[k];
+      bool seen = false;
+      for (int q = 0; q < min(n, SMX_RW_LANE_CAP); ++q) seen = seen || lane[q] == ln;
+      if (seen) continue;
+      if (n < SMX_RW_LANE_CAP) lane[n] = ln;
+      ++n;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_road_waypoints(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const smx_outputs& o = a.out;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t tid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  const size_t gid = tid / SMX_RW_LANE_CAP;
+  const int l = (int)(tid % SMX_RW_LANE_CAP);
+  if (gid >= total) return;
+  const int flags = a.st.flags[gid];
+  if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL) || (a.first_only && !(flags & SMX_F_FIRST))) return;
+  const int L = c.rw_lanes, P = c.rw_paths, H = c.rw_horizon, R = 2 * H + 1;
+  const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
+  // ---- the sensor's lanes: nearest lane's road, its parallel roads, the roads oncoming at the point
+  RwLanes lanes;
+  lanes.n = 0;
+  // road_map.nearest_lane(point) (road_map.py:91-96, the default radius); asked here rather than taken from
+  // k_scan so that the kernel also serves the reset pass, whose scan runs inside k_first
+  const RoadFacts nf = road_facts_scan(m, px, py, fmax(10.0, 2.0 * m.default_lane_width), 0, nullptr, nullptr);
+  if (nf.lane >= 0) {
+    const int road = m.lane_road[nf.lane];
+    lanes.add_road(m, road);
+    for (int k = m.road_par_off[road]; k < m.road_par_off[road + 1]; ++k) lanes.add_road(m, m.road_par_idx[k]);
+    // Road.oncoming_roads_at_point (sumo_road_network.py:596-605)
+    for (int k = m.road_lane_off[road]; k < m.road_lane_off[road + 1]; ++k) {
+      const int ln = m.road_lanes[k];
+      const double off = lane_offset_along(m, ln, px, py);
+      oncoming_lanes_at_offset(m, ln, off, [&](int other) {
+        if (m.lane_road[other] != road) lanes.add_road(m, m.lane_road[other]);
+      });
+    }
+  }
+  if (l == 0) o.rw_lane_count[gid] = (uint8_t)min(lanes.n, 255);
+  if (l >= L) return;
+  const size_t lane_row = gid * (size_t)L + l;
+  const bool mine = l < min(lanes.n, SMX_RW_LANE_CAP);
+  int my_lane = -1;
+#pragma unroll
+  for (int q = 0; q < SMX_RW_LANE_CAP; ++q)
+    if (q == l && mine) my_lane = lanes.lane[q];
+  o.rw_lane[lane_row] = (int16_t)my_lane;
+  int n_paths = 0;
+  if (my_lane >= 0) {
+    RouteFilter f;  // route = plan.route: a fixed route filters, the endless mission's empty route does not
+    f.fixed_route(a.missions, (int)(gid % (size_t)c.num_vehicles), m.n_roads);
+    // ---- paths_for_lane (sensors.py:1014-1040): depth first through the incoming lanes
+    int st_lane[SMX_RW_STACK];
+    double st_start[SMX_RW_STACK];
+    int sp = 0;
+    st_lane[sp] = my_lane;
+    st_start[sp] = lane_offset_along(m, my_lane, px, py) - (double)H;
+    ++sp;
+    int knots[SMX_RW_MAX_KNOTS];
+    while (sp > 0) {
+      --sp;
+      const int ln = st_lane[sp];
+      double start_offset = st_start[sp];
+      const int ia = m.lane_in_off[ln], ib = m.lane_in_off[ln + 1];
+      if (start_offset < 0.0 && ib > ia) {
+        // children in reverse so that the first incoming lane is taken up first (a full stack drops the rest:
+        // rows of at most rw_paths paths are kept anyway, the count then reads low)
+        for (int k = ib - 1; k >= ia; --k) {
+          if (sp >= SMX_RW_STACK) break;
+          const int child = m.lane_in_idx[k];
+          st_lane[sp] = child;
+          st_start[sp] = m.lane_length[child] + start_offset;
+          ++sp;
+        }
+        continue;
+      }
+      start_offset = fmax(0.0, start_offset);
+      double wx, wy;
+      lane_point_at_offset(m, ln, start_offset, wx, wy);
+      int key[4] = {ln, -9, -9, -9};
+      int idx4[4];
+      closest_filtered4(m, wx, wy, key, 1, false, idx4, nullptr);
+      const int start = idx4[0];
+      if (start < 0) continue;
+      BranchState bs;
+      bs.reset();
+      do {
+        const bool kept = n_paths < P;
+        const size_t row = (lane_row * (size_t)P + (size_t)(kept ? n_paths : 0)) * (size_t)R;
+        const int n = equally_spaced_path<SMX_RW_MAX_KNOTS>(m, f, bs, start, 2 * H, wx, wy, knots, 1, kept ? R : 0,
+                                                            [&](int i, const WaypointOut& w) {
+                                                              double* d = o.rw_pos + (row + i) * 3;
+                                                              d[0] = w.x;
+                                                              d[1] = w.y;
+                                                              d[2] = 0.0;
+                                                              o.rw_heading[row + i] = (float)w.heading;
+                                                              o.rw_lane_width[row + i] = (float)w.width;
+                                                              o.rw_speed_limit[row + i] = (float)w.speed;
+                                                              o.rw_lane_index[row + i] = (int8_t)m.lane_index[w.lane];
+                                                              o.rw_lane_id[row + i] = (int16_t)w.lane;
+                                                            });
+        if (kept) o.rw_count[lane_row * (size_t)P + n_paths] = (uint8_t)min(n, R);
+        if (n_paths < 32767) ++n_paths;
+      } while (bs.advance());
+    }
+  }
+  o.rw_path_count[lane_row] = (int16_t)n_paths;
+  for (int p = min(n_paths, P); p < P; ++p) o.rw_count[lane_row * (size_t)P + p] = 0;
+}
+
 // The reset pass of the grid sensors: almost no vehicle is new in a given tick, and one workgroup
 // per vehicle that only finds that out costs ~120 us at 131 k vehicles.  Here a workgroup looks at
 // the flags of 64 vehicles with one load and a ballot, and builds tiles only for the new ones.
@@ -3194,6 +3327,10 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   if (c.num_envs <= 0 || c.num_vehicles <= 0 || c.num_vehicles > SMX_BLOCK)
     return fail(h, SMX_ERR_INVALID, "num_envs must be > 0 and 0 < num_vehicles <= 64");
   if (!(c.dt > 0.0)) return fail(h, SMX_ERR_INVALID, "dt must be > 0");
+  if ((c.sensors & SMX_SENSOR_ROAD_WAYPOINTS) &&
+      (c.rw_horizon < 1 || c.rw_horizon > SMX_RW_HORIZON_MAX || c.rw_lanes < 1 || c.rw_lanes > SMX_RW_LANE_CAP || c.rw_paths < 1 ||
+       c.rw_paths > 64))
+    return fail(h, SMX_ERR_INVALID, "road waypoints: need 1 <= rw_horizon <= 64, 1 <= rw_lanes <= 8, 1 <= rw_paths <= 64");
   if ((c.sensors & SMX_SENSOR_WAYPOINTS) &&
       (c.wp_lookahead < 1 || c.wp_lookahead > SMX_MAX_KNOTS - 2 || c.wp_paths < 1 || c.wp_paths > 64 || c.wp_len < 1 || c.wp_len > c.wp_lookahead + 1))
     return fail(h, SMX_ERR_INVALID, "waypoints: need lookahead >= 1, 1 <= wp_paths <= 64, 1 <= wp_len <= lookahead + 1");
@@ -3581,6 +3718,8 @@ static int check_buffers_impl(const smx_config& c, bool has_vias, bool need_lida
   const bool wp = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0, nb = (c.sensors & SMX_SENSOR_NEIGHBORS) != 0;
   const bool ogm = (c.sensors & SMX_SENSOR_OGM) != 0, dagm = (c.sensors & SMX_SENSOR_DAGM) != 0;
   const bool lidar = (c.sensors & SMX_SENSOR_LIDAR) != 0, vias = c.via_max > 0 && has_vias;
+  const bool rw = (c.sensors & SMX_SENSOR_ROAD_WAYPOINTS) != 0;
+  const uint64_t RWL = rw ? (uint64_t)c.rw_lanes : 0, RWP = rw ? (uint64_t)c.rw_paths : 0, RWR = rw ? 2 * (uint64_t)c.rw_horizon + 1 : 0;
   const uint64_t PW = (uint64_t)c.wp_paths * c.wp_len, K = (uint64_t)c.nb_max, R = (uint64_t)c.lidar_rays;
 #define ST(field, idx, need, want, req) \
   {"state." #field, st->field, st->count[idx], st->dtype[idx], (uint64_t)(need), want, req}
@@ -3634,6 +3773,16 @@ static int check_buffers_impl(const smx_config& c, bool has_vias, bool need_lida
       OUT(lidar_point, SMX_OUT_LIDAR_POINT, T * R * 3, SMX_DT_F64, lidar),
       OUT(dagm, SMX_OUT_DAGM, T * (uint64_t)c.dagm_width * c.dagm_height, SMX_DT_U8, dagm),
       OUT(collidees, SMX_OUT_COLLIDEES, T, SMX_DT_U64, false),
+      OUT(rw_lane_count, SMX_OUT_RW_LANE_COUNT, T, SMX_DT_U8, rw),
+      OUT(rw_lane, SMX_OUT_RW_LANE, T * RWL, SMX_DT_I16, rw),
+      OUT(rw_path_count, SMX_OUT_RW_PATH_COUNT, T * RWL, SMX_DT_I16, rw),
+      OUT(rw_count, SMX_OUT_RW_COUNT, T * RWL * RWP, SMX_DT_U8, rw),
+      OUT(rw_pos, SMX_OUT_RW_POS, T * RWL * RWP * RWR * 3, SMX_DT_F64, rw),
+      OUT(rw_heading, SMX_OUT_RW_HEADING, T * RWL * RWP * RWR, SMX_DT_F32, rw),
+      OUT(rw_lane_width, SMX_OUT_RW_LANE_WIDTH, T * RWL * RWP * RWR, SMX_DT_F32, rw),
+      OUT(rw_speed_limit, SMX_OUT_RW_SPEED_LIMIT, T * RWL * RWP * RWR, SMX_DT_F32, rw),
+      OUT(rw_lane_index, SMX_OUT_RW_LANE_INDEX, T * RWL * RWP * RWR, SMX_DT_I8, rw),
+      OUT(rw_lane_id, SMX_OUT_RW_LANE_ID, T * RWL * RWP * RWR, SMX_DT_I16, rw),
   };
 #undef ST
 #undef OUT
@@ -3836,6 +3985,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         (void)hipStreamWaitEvent(stream, h->ev_join[i], 0);
       }
     }
+    if (c.sensors & SMX_SENSOR_ROAD_WAYPOINTS)  // (poses are the tick's new ones; flags still those of its start)
+      hipLaunchKernelGGL(k_road_waypoints, dim3((unsigned)((total * SMX_RW_LANE_CAP + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0,
+                         stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_SENSORS + 1], stream);
     hipLaunchKernelGGL(k_commit, dim3(obs_blocks), dim3(SMX_BLOCK), 0, stream, k);
     if (phases && phased) (void)hipEventRecord(ph[SMX_PHASE_COMMIT + 1], stream);
@@ -3910,6 +4062,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     const unsigned sweep_blocks = (unsigned)((total + SMX_BLOCK - 1) / SMX_BLOCK);
     if (ogm_bytes) hipLaunchKernelGGL(k_grid_first<false>, dim3(sweep_blocks), dim3(SMX_BLOCK), ogm_bytes, stream, r);
     if (dagm_bytes) hipLaunchKernelGGL(k_grid_first<true>, dim3(sweep_blocks), dim3(SMX_BLOCK), dagm_bytes, stream, r);
+    if (c.sensors & SMX_SENSOR_ROAD_WAYPOINTS)  // before k_first clears SMX_F_FIRST
+      hipLaunchKernelGGL(k_road_waypoints, dim3((unsigned)((total * SMX_RW_LANE_CAP + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0,
+                         stream, r);
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());

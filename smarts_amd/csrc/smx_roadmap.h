@@ -757,7 +757,7 @@ __device__ __forceinline__ void interpolate_knots_preloaded(const MapDev& m, con
   }
 }
 
-template <class Emit>
+template <int MAXK = SMX_MAX_KNOTS, class Emit>
 __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f, BranchState& bs, int start,
                                           int lookahead, double px, double py, int* knots, int kstride,
                                           int max_emit, Emit&& emit) {
@@ -779,8 +779,8 @@ __device__ inline int equally_spaced_path(const MapDev& m, const RouteFilter& f,
     for (;;) {
       int idx = w.next(m, f, bs, rec, last);
       if (idx < 0) break;
-      if (nk < SMX_MAX_KNOTS) knots[nk * kstride] = idx;
-      (void)SMX_BCHK(16, nk, SMX_MAX_KNOTS);
+      if (nk < MAXK) knots[nk * kstride] = idx;
+      (void)SMX_BCHK(16, nk, MAXK);
       ++nk;
       double ex = rec.x - lastx, ey = rec.y - lasty;
       D += sqrt(ex * ex + ey * ey);

@@ -705,6 +705,86 @@ __device__ inline bool oncoming_lane_on_route(const MapDev& m, const RouteFilter
   return false;
 }
 
+// Lane.oncoming_lanes_at_offset(offset) (sumo_road_network.py:371-395) in the reference's order: the lanes
+// nearest_lanes(pt, 1.1 x width) finds — sorted by centre-line distance, equal distances in lane-table order
+// (the stable sort over sumolib's _allLanes order) — that run against this lane.  visit(lane) per result.
+#define SMX_ONCOMING_CAP 16
+template <class Visit>
+__device__ inline void oncoming_lanes_at_offset(const MapDev& m, int lane, double offset, Visit&& visit) {
+  const double radius = 1.1 * m.lane_width[lane];
+  double ptx, pty;
+  lane_point_at_offset(m, lane, offset, ptx, pty);
+  double mvx, mvy;
+  lane_vector_at_offset(m, lane, offset, mvx, mvy);
+  const double my_norm = sqrt(mvx * mvx + mvy * mvy + 0.0);
+  int cand[SMX_ONCOMING_CAP];
+  double cdist[SMX_ONCOMING_CAP];
+  int nc = 0;
+  int cx0 = (int)floor((ptx - radius - m.sg_x0) / m.sg_cell), cx1 = (int)floor((ptx + radius - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((pty - radius - m.sg_y0) / m.sg_cell), cy1 = (int)floor((pty + radius - m.sg_y0) / m.sg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.sg_nx - 1);
+  cy1 = min(cy1, m.sg_ny - 1);
+  for (int gy = cy0; gy <= cy1; ++gy) {
+    const int row = gy * m.sg_nx;
+    const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
+    for (int k = a; k < b; ++k) {
+      const smx_seg_rec s = m.sg_rec[k];
+      const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
+      const double d = sqrt(ex * ex + ey * ey);
+      const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
+      const double u = ((ptx - s.x1) * sx) + ((pty - s.y1) * sy);
+      const double off = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+      double dist;
+      if (off == 0.0) {
+        dist = sqrt((ptx - s.x1) * (ptx - s.x1) + (pty - s.y1) * (pty - s.y1));
+      } else {
+        const double uu = off / d;
+        const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
+        dist = sqrt((ptx - ix) * (ptx - ix) + (pty - iy) * (pty - iy));
+      }
+      if (!(dist < radius)) continue;
+      int at = -1;
+      for (int q = 0; q < nc; ++q)
+        if (cand[q] == s.lane) at = q;
+      if (at >= 0) {
+        cdist[at] = fmin(cdist[at], dist);
+      } else if (nc < SMX_ONCOMING_CAP) {
+        cand[nc] = s.lane;
+        cdist[nc] = dist;
+        ++nc;
+      }
+    }
+  }
+  if (nc == 0 || my_norm == 0.0) return;
+  // order: (distance, lane index)
+  for (int i = 1; i < nc; ++i) {
+    const int cl = cand[i];
+    const double cd = cdist[i];
+    int j = i - 1;
+    while (j >= 0 && (cdist[j] > cd || (cdist[j] == cd && cand[j] > cl))) {
+      cand[j + 1] = cand[j];
+      cdist[j + 1] = cdist[j];
+      --j;
+    }
+    cand[j + 1] = cl;
+    cdist[j + 1] = cd;
+  }
+  const double threshold = -0.995562;  // cos(175 deg)
+  for (int q = 0; q < nc; ++q) {
+    const int other = cand[q];
+    if (other == lane) continue;
+    const double ls = lane_offset_along(m, other, ptx, pty);
+    double lvx, lvy;
+    lane_vector_at_offset(m, other, ls, lvx, lvy);
+    const double lv_norm = sqrt(lvx * lvx + lvy * lvy + 0.0);
+    if (lv_norm == 0.0) continue;
+    const double lane_angle = (mvx * lvx + mvy * lvy + 0.0) / (my_norm * lv_norm);
+    if (lane_angle < threshold) visit(other);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Lane.center_at_point (road_map.py:357-360): from_lane_coord(offset_along_lane(point)) — the point of
 // the lane's centre line closest to (px, py).  One-lane form (the via sensor asks it for a handful of

@@ -66,6 +66,12 @@ class SimConfig:
     social_model: str = "constant"  # "constant" | "idm" (include/smx.h SMX_SOCIAL_*)
     action_space: str = "Lane"  # ActionSpaceType name: Lane | Continuous | ActuatorDynamic | LaneWithContinuousSpeed
     launch_strategy: str = "auto"  # "auto" | "small" | "large": how a tick is cut into launches (include/smx.h)
+    # RoadWaypoints (agent_interface.py RoadWaypoints.horizon = 32; sensors.py:991-1040): dense rows keep the first
+    # rw_lanes lanes and the first rw_paths paths of each, 2 x horizon + 1 waypoints per path
+    road_waypoints: bool = False
+    rw_horizon: int = 32
+    rw_lanes: int = 8
+    rw_paths: int = 4
 
     def sensors_mask(self) -> int:
         m = 0
@@ -81,6 +87,8 @@ class SimConfig:
             m |= nat.SENSOR_LIDAR
         if self.dagm:
             m |= nat.SENSOR_DAGM
+        if self.road_waypoints:
+            m |= nat.SENSOR_ROAD_WAYPOINTS
         return m
 
     def done_mask(self) -> int:
@@ -229,6 +237,8 @@ class BatchedSim:
             c.lidar_rays, c.lidar_max_distance = ray_count(cfg.lidar), cfg.lidar.max_distance
         if cfg.dagm:
             c.dagm_width, c.dagm_height, c.dagm_resolution = cfg.dagm_width, cfg.dagm_height, cfg.dagm_resolution
+        if cfg.road_waypoints:
+            c.rw_horizon, c.rw_lanes, c.rw_paths = int(cfg.rw_horizon), int(cfg.rw_lanes), int(cfg.rw_paths)
         self._c = c
         self.handle = C.c_void_p()
         rc = self.lib.smx_create(C.byref(c), idx, C.byref(self.handle))
@@ -340,6 +350,18 @@ class BatchedSim:
             o["ogm"] = z((E, N, cfg.ogm_height, cfg.ogm_width), torch.uint8)
         if cfg.dagm:
             o["dagm"] = z((E, N, cfg.dagm_height, cfg.dagm_width), torch.uint8)
+        if cfg.road_waypoints:
+            L, Q, R = cfg.rw_lanes, cfg.rw_paths, 2 * cfg.rw_horizon + 1
+            o["rw_lane_count"] = z((E, N), torch.uint8)
+            o["rw_lane"] = torch.full((E, N, L), -1, dtype=torch.int16, device=dev)
+            o["rw_path_count"] = z((E, N, L), torch.int16)
+            o["rw_count"] = z((E, N, L, Q), torch.uint8)
+            o["rw_pos"] = z((E, N, L, Q, R, 3), torch.float64)
+            o["rw_heading"] = z((E, N, L, Q, R), torch.float32)
+            o["rw_lane_width"] = z((E, N, L, Q, R), torch.float32)
+            o["rw_speed_limit"] = z((E, N, L, Q, R), torch.float32)
+            o["rw_lane_index"] = z((E, N, L, Q, R), torch.int8)
+            o["rw_lane_id"] = z((E, N, L, Q, R), torch.int16)
         if cfg.lidar is not None:
             R = ray_count(cfg.lidar)
             o["lidar_hit"] = z((E, N, R), torch.uint8)
@@ -385,7 +407,7 @@ class BatchedSim:
         ctrl_state = 14 * 8 + 4  # SMX_S_X .. SMX_S_MCL_Y + flags: read and written back by k_control
         obs_state_r, obs_state_w = 16 * 8 + 4 + 4, 12 * 8 + 4  # trip meter / accelerometer / driven-path fields, steps
         wp = sum(v for k, v in o.items() if k.startswith("wp_")) if self.cfg.waypoints else 0
-        rows = sum(v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar", "dagm"))) + 8  # + learner block
+        rows = sum(v for k, v in o.items() if not k.startswith(("wp_", "ogm", "lidar", "dagm", "rw_"))) + 8  # + learner block
         kb = {
             "control": (ctrl_state + (12 if self.cfg.action_space != "Lane" else 1), ctrl_state + 2 * 8),
             "scan": (pose, 0),

@@ -28,6 +28,7 @@ def oracle_config(cfg):
         ogm=(cfg.ogm_width, cfg.ogm_height, cfg.ogm_resolution) if cfg.ogm else None,
         dagm=(cfg.dagm_width, cfg.dagm_height, cfg.dagm_resolution) if cfg.dagm else None,
         lidar_rays=oracle_lidar_rays(cfg.lidar) if cfg.lidar is not None else None,
+        road_waypoints_horizon=cfg.rw_horizon if cfg.road_waypoints else None,
     )
 
 
@@ -66,6 +67,14 @@ def empty_dense(cfg, n):
         d["ogm"] = np.zeros((n, cfg.ogm_height, cfg.ogm_width), np.uint8)
     if cfg.dagm:
         d["dagm"] = np.zeros((n, cfg.dagm_height, cfg.dagm_width), np.uint8)
+    if cfg.road_waypoints:
+        L, Q, R = cfg.rw_lanes, cfg.rw_paths, 2 * cfg.rw_horizon + 1
+        d.update(
+            rw_lane_count=np.zeros(n, np.uint8), rw_lane=np.full((n, L), -1, np.int16), rw_path_count=np.zeros((n, L), np.int16),
+            rw_count=np.zeros((n, L, Q), np.uint8), rw_pos=np.zeros((n, L, Q, R, 3)), rw_heading=np.zeros((n, L, Q, R), np.float32),
+            rw_lane_width=np.zeros((n, L, Q, R), np.float32), rw_speed_limit=np.zeros((n, L, Q, R), np.float32),
+            rw_lane_index=np.zeros((n, L, Q, R), np.int8), rw_lane_id=np.zeros((n, L, Q, R), np.int16),
+        )
     if cfg.lidar is not None:
         from smarts_amd.lidar import ray_count
 
@@ -137,6 +146,21 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
             d["via_near_count"][i] = min(len(near), 255)
             d["via_near"][i, :min(len(near), cfg.via_max)] = near[:cfg.via_max]
             d["via_hit"][i] = sum(1 << k for k in hit)
+        if cfg.road_waypoints:
+            lanes = o["road_waypoints"]  # {lane id: [paths]} in the reference's dict order
+            d["rw_lane_count"][i] = min(len(lanes), 255)
+            for l, (lane_id, paths) in enumerate(list(lanes.items())[: cfg.rw_lanes]):
+                d["rw_lane"][i, l] = lane_no[lane_id]
+                d["rw_path_count"][i, l] = min(len(paths), 32767)
+                for p, path in enumerate(paths[: cfg.rw_paths]):
+                    d["rw_count"][i, l, p] = len(path)
+                    for w, wp in enumerate(path):
+                        d["rw_pos"][i, l, p, w, :2] = wp.pos
+                        d["rw_heading"][i, l, p, w] = wp.heading
+                        d["rw_lane_width"][i, l, p, w] = wp.lane_width
+                        d["rw_speed_limit"][i, l, p, w] = wp.speed_limit
+                        d["rw_lane_index"][i, l, p, w] = wp.lane_index
+                        d["rw_lane_id"][i, l, p, w] = lane_no[wp.lane_id]
         if cfg.ogm:
             d["ogm"][i] = o["ogm"]
         if cfg.dagm:
@@ -150,7 +174,8 @@ def pack(cfg, lane_no, n, obs, rewards=None, dones=None):
 
 INT_KEYS = ["ego_lane", "events", "done", "active", "wp_lane_index", "wp_lane_id", "wp_count", "nb_lane_index",
             "nb_lane_id", "nb_slot", "nb_count", "ogm", "dagm", "lidar_hit", "via_near", "via_near_count", "via_hit",
-            "collidees"]
+            "collidees", "rw_lane_count", "rw_lane", "rw_path_count", "rw_count", "rw_lane_index", "rw_lane_id"]
+RW_ROWS = ["rw_pos", "rw_heading", "rw_lane_width", "rw_speed_limit", "rw_lane_index", "rw_lane_id"]
 
 
 def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
@@ -160,6 +185,11 @@ def compare(dev, ora, tol64=1e-9, tol32=2e-5, where=""):
         b = dev[k]
         if k == "collidees":
             b = np.ascontiguousarray(b).view(np.uint64)  # the device tensor is int64 (torch has no uint64 arithmetic)
+        if k in RW_ROWS:
+            # rows beyond a path's count are not written by the device (include/smx.h): compared where counted
+            R = ora["rw_count"].astype(np.int64)[..., None] > np.arange(a.shape[3])
+            keep = R if a.ndim == 4 else R[..., None]
+            a, b = np.where(keep, a, 0), np.where(keep, b, 0)
         if k in INT_KEYS:
             if not np.array_equal(a, b):
                 idx = np.argwhere(a != b)[:4]
