@@ -225,15 +225,16 @@ class AgentInterface:
     def validate_for_device(self):
         """Raise for anything the MI355X path does not implement (the Lane,
         Continuous, ActuatorDynamic, LaneWithContinuousSpeed and Trajectory action spaces and the waypoints /
-        neighbourhood / accelerometer / OGM / drivable-area grid map / lidar sensors)."""
+        neighbourhood / accelerometer / OGM / drivable-area grid map / lidar / road-waypoints sensors)."""
         # action=None (AgentType.Buddha) needs no controller: the vehicle is never given a command
         if self.action is not None and self.action not in DEVICE_ACTION_SPACES:
             raise NotImplementedError(
                 f"action space {self.action} is not on the accelerated path "
                 f"(supported: {[a.name for a in DEVICE_ACTION_SPACES]})")
-        for name in ("road_waypoints", "rgb"):
-            if getattr(self, name):
-                raise NotImplementedError(f"AgentInterface.{name} is not on the accelerated path")
+        if self.rgb:
+            raise NotImplementedError("AgentInterface.rgb is not on the accelerated path")
+        if self.road_waypoints and not 1 <= self.road_waypoints.horizon <= 64:
+            raise NotImplementedError("RoadWaypoints.horizon must be 1..64 on the accelerated path (include/smx.h)")
         if self.vehicle_type != "sedan":
             raise NotImplementedError("only the sedan chassis is modelled")
         alive = self.done_criteria.agents_alive

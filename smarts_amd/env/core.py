@@ -121,6 +121,8 @@ def sim_config_from_interface(itf: AgentInterface, num_envs: int, num_agents: in
         kw.update(dagm=True, dagm_width=g.width, dagm_height=g.height, dagm_resolution=g.resolution)
     if itf.lidar:
         kw.update(lidar=itf.lidar.sensor_params)
+    if itf.road_waypoints:
+        kw.update(road_waypoints=True, rw_horizon=itf.road_waypoints.horizon)
     return SimConfig(**kw)
 
 
@@ -186,7 +188,8 @@ class BatchCore:
         self.builder = ObservationBuilder(
             self.cm.lane_ids, road_ids, vehicle_names, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
             accelerometer=self.cfg.accelerometer, ogm=first.ogm or None, dagm=first.drivable_area_grid_map or None,
-            lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias)
+            lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias,
+            road_waypoints=bool(first.road_waypoints))
         self._was_reset = False
         self._destroyed = False
 

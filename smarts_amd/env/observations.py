@@ -205,6 +205,14 @@ class Observation:
     via_data: Vias
 
 
+class RoadWaypoints(NamedTuple):
+    """sensors.py:104-107: per lane id (of the ego road, its parallel roads and the roads oncoming at the vehicle)
+    the waypoint paths that start ``horizon`` behind the vehicle.  From the dense rows: the first ``rw_lanes`` lanes
+    and the first ``rw_paths`` paths of each (include/smx.h)."""
+
+    lanes: Dict[str, List[List[Waypoint]]]
+
+
 @dataclass(frozen=True)
 class EndlessMission:
     """What ``hiway-v0`` assigns an agent without ``missions.pkl`` (scenario.py:289-290,
@@ -220,13 +228,14 @@ class ObservationBuilder:
 
     def __init__(self, lane_ids: Sequence[str], lane_road_ids: Sequence[str], agent_ids: Sequence[str], *,
                  waypoints: bool, neighbors: bool, accelerometer: bool, ogm=None, lidar_rays: Optional[np.ndarray] = None,
-                 dt: float = 0.1, vias=None, dagm=None):
+                 dt: float = 0.1, vias=None, dagm=None, road_waypoints: bool = False):
         self.lane_ids = list(lane_ids)
         self.lane_road_ids = list(lane_road_ids)
         self.agent_ids = list(agent_ids)
         self.waypoints, self.neighbors, self.accelerometer = waypoints, neighbors, accelerometer
         self.ogm, self.lidar_rays, self.dt = ogm, lidar_rays, dt
         self.dagm = dagm
+        self.road_waypoints = road_waypoints
         self.vias = vias  # per vehicle slot: resolved mission vias (smarts_amd.vias.ResolvedVia)
 
     def vehicle_id(self, slot: int) -> str:
@@ -305,6 +314,25 @@ class ObservationBuilder:
                         speed_limit=float(rows["wp_speed_limit"][slot, p, w]),
                         lane_index=int(rows["wp_lane_index"][slot, p, w])))
                 paths.append(path)
+        road_wps = None
+        if self.road_waypoints:
+            lanes = {}
+            for l, lane in enumerate(rows["rw_lane"][slot]):
+                if lane < 0:
+                    continue
+                lane_paths = []
+                for p, n in enumerate(rows["rw_count"][slot, l]):
+                    if p >= int(rows["rw_path_count"][slot, l]):
+                        break
+                    lane_paths.append([Waypoint(
+                        pos=np.array(rows["rw_pos"][slot, l, p, w, :2], dtype=np.float64),
+                        heading=Heading(float(rows["rw_heading"][slot, l, p, w])),
+                        lane_id=self.lane_ids[int(rows["rw_lane_id"][slot, l, p, w])],
+                        lane_width=float(rows["rw_lane_width"][slot, l, p, w]),
+                        speed_limit=float(rows["rw_speed_limit"][slot, l, p, w]),
+                        lane_index=int(rows["rw_lane_index"][slot, l, p, w])) for w in range(int(n))])
+                lanes[self.lane_ids[int(lane)]] = lane_paths
+            road_wps = RoadWaypoints(lanes=lanes)
         ogm = None
         if self.ogm is not None:
             meta = GridMapMetadata(
@@ -342,4 +370,4 @@ class ObservationBuilder:
             dt=self.dt, step_count=step_count, elapsed_sim_time=elapsed_sim_time, events=events, ego_vehicle_state=ego,
             neighborhood_vehicle_states=neighbors, waypoint_paths=paths, distance_travelled=float(rows["dist"][slot]),
             lidar_point_cloud=lidar, drivable_area_grid_map=dagm, occupancy_grid_map=ogm, top_down_rgb=None,
-            road_waypoints=None, via_data=via_data)
+            road_waypoints=road_wps, via_data=via_data)

@@ -104,3 +104,28 @@ def test_road_waypoints_rollout_against_the_oracle(strategy, nets, compiled_maps
         parity.sync_oracle_from_device(ob, sim)
     sim.close()
     assert seen_lanes >= 4  # the oncoming road's lanes are reported beside the ego road's
+
+
+def test_hiway_env_road_waypoints_observation():
+    """gym surface: AgentInterface(road_waypoints=RoadWaypoints(horizon)) -> Observation.road_waypoints.lanes keyed by
+    lane id, every path starting `horizon` behind the vehicle and 2 x horizon + 1 waypoints long where the road goes on."""
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+    from smarts_amd.env.agent_interface import RoadWaypoints
+
+    itf = AgentInterface.from_type(AgentType.Laner, road_waypoints=RoadWaypoints(horizon=16), max_episode_steps=50)
+    spec = AgentSpec(interface=itf, agent_builder=lambda: Agent.from_function(lambda _: "keep_lane"))
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs={"A": spec}, seed=11)
+    obs = env.reset()
+    for _ in range(3):
+        rw = obs["A"].road_waypoints
+        ego = obs["A"].ego_vehicle_state
+        assert ego.lane_id in rw.lanes and len(rw.lanes) >= 2  # the ego road's lanes
+        for lane_id, paths in rw.lanes.items():
+            assert len(paths) >= 1
+            for path in paths:
+                assert 1 <= len(path) <= 33
+                # the paths reach back behind the vehicle: the first waypoint lies ~horizon metres from it
+                d0 = np.linalg.norm(path[0].pos - ego.position[:2])
+                assert d0 > 8.0, (lane_id, d0)
+        obs, _, _, _ = env.step({"A": "keep_lane"})
+    env.close()
