@@ -220,10 +220,11 @@ def test_trip_meter_matches_reference(sensor_golden, oracle_maps):
     # TripMeterSensor.__init__: first waypoint of waypoint_paths(pose, lookahead=1, within_radius=length)
     first = rmap.waypoint_paths(np.array([poses[0][0], poses[0][1], 0.0]), poses[0][2], lookahead=1, within_radius=3.68)[0][0]
     assert np.array_equal(np.array([first.pos[0], first.pos[1], float(first.heading)]), g["trip_first_wp"])
-    ag = types.SimpleNamespace(wps_for_distance=[first], dist_travelled=0.0, last_dist_travelled=0.0)
+    ag = types.SimpleNamespace(wps_for_distance=[first], dist_travelled=0.0, last_dist_travelled=0.0, route=(), goal=None)
+    env = types.SimpleNamespace(road_map=rmap)
     for k, (x, y, h) in enumerate(poses):
         wp = rmap.waypoint_paths(np.array([x, y, 0.0]), h, lookahead=32, route=None)[0][0]
-        OracleEnv._append_waypoint_if_new(None, ag, wp)
+        OracleEnv._append_waypoint_if_new(env, ag, wp)
         assert ag.dist_travelled == g["trip_total"][k], k
         assert ag.dist_travelled - ag.last_dist_travelled == g["trip_inc"][k], k
     assert g["trip_inc"].min() < 0 < g["trip_inc"].max()  # the reverse hop counts negative
