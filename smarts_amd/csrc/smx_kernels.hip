@@ -1583,9 +1583,14 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
         bs.reset();
         int below16 = 0;        // knots less than 16 hops down
         bool knot_at_16 = false;
+        int base_idx = start, base_hop = 0;  // the last lanepoint of the list less than 16 hops down (the start if no knot is)
         const PathWalk w = walk_knots(m, seed.f, bs, start, c.wp_lookahead, px, py, [&](int k, int idx, int hop) {
           if (k <= SMX_WPK_CAP) a.knots.idx[(size_t)k * paths + path] = idx;
-          if (hop < SMX_CTRL_WPS - 1) ++below16;
+          if (hop < SMX_CTRL_WPS - 1) {
+            ++below16;
+            base_idx = idx;
+            base_hop = hop;
+          }
           if (hop == SMX_CTRL_WPS - 1) knot_at_16 = true;
         });
         n = w.n;
@@ -1594,14 +1599,21 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
         // the lookahead-16 path: the whole path when it is no longer than that, else the knots less than 16
         // hops down and the lanepoint 16 hops down (a knot of the list, or the probed interpolated lanepoint)
         a.knots.nk16[path] = (uint8_t)(w.n <= SMX_CTRL_WPS ? w.nk : below16 + 1);
-        // (found by a walk of its own, a handful of knot steps: noting it from inside the long walk — a probe in
-        // KnotWalk::next — made hipcc 7.2.0 drop the walk step the probe fired in on gfx950 whenever a route filter
-        // left one of several successors: profiles/r02_next0_investigation.txt, case 2)
+        // (an interpolated lanepoint of the run that leaves the last knot before it: followed here, after the walk,
+        // from that knot's record — the successor the route filter allows where the knot branches; the list is only
+        // reused when exactly one path starts on this seed lane, so there is exactly one)
         int end16 = -1;
         if (w.n > SMX_CTRL_WPS && !knot_at_16) {
-          BranchState b16;
-          b16.reset();
-          walk_knots(m, seed.f, b16, start, SMX_CTRL_WPS - 1, px, py, [&](int, int idx, int) { end16 = idx; });
+          const smx_lp_rec br = load_lp(m, base_idx, 47);
+          int first = br.next0;
+          if (br.n_next > 1) {
+            first = -1;
+            for (int k = br.next_off; k < br.next_off + br.n_next && first < 0; ++k) {
+              const smx_succ_rec sr = m.succ_rec[k];
+              if (lane_allowed(m, seed.f, sr.lane)) first = sr.idx;
+            }
+          }
+          if (first >= 0) end16 = chain_at(m, first, SMX_CTRL_WPS - 1 - base_hop - 1, (br.flags & 1) != 0);
         }
         a.knots.end16[path] = end16;
         a.knots.key[path] = start;

@@ -213,3 +213,50 @@ def test_hiway_env_mission_ends_at_its_goal():
             break
     assert reached, ticks
     env.close()
+
+
+@pytest.mark.parametrize("strategy", ["small", "large"])
+def test_fixed_route_rollout_on_minicity(strategy, nets, compiled_maps):
+    """Routes of the reference-generated fixture (several junctions each) driven on the big map: every output of
+    every tick against the oracle, teacher-forced; one agent of three keeps an endless mission."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig
+    from smarts_amd.missions import Mission, Route, plan_mission
+
+    cm, net = compiled_maps("minicity"), nets("minicity")
+    g = np.load(os.path.join(GOLDEN, "missions_minicity.npz"))
+    off = g["route_off"]
+    missions = []
+    for k in (1, 2):
+        a, b = (str(x) for x in g["route_pairs"][k])
+        m = plan_mission(net, Mission(Route(begin=(a, 0, 3.0), end=(b, 0, "max"))))
+        assert list(m.route_roads) == [str(r) for r in g["route_roads"][off[k]:off[k + 1]]]  # the planner, end to end
+        missions.append(m)
+    missions.append(None)
+    E, N = 2, 3
+    spawns = np.zeros((1, E * N, 4))
+    free = missions[0].spawn_pose()
+    for e in range(E):
+        for i, m in enumerate(missions):
+            x, y, h = m.spawn_pose() if m is not None else (free[0] + 7.0 * np.sin(free[2]), free[1] - 7.0 * np.cos(free[2]), free[2])
+            spawns[0, e * N + i] = (x, y, h, 7.0 + 2 * e)
+    cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, launch_strategy=strategy)
+    sim = BatchedSim(cm, cfg, spawns=spawns, missions=missions)
+    ob = parity.OracleBatch(net, cm, cfg, spawns[0], missions=missions)
+
+    def host(out):
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy().reshape((-1,) + tuple(v.shape[2:])) for k, v in out.items() if k != "env_done"}
+
+    d, o = host(sim.reset()), ob.reset_observe()
+    assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
+    rng = np.random.default_rng(17)
+    for t in range(70):
+        acts = np.where(rng.random((E, N)) < 0.85, 0, rng.integers(1, 4, (E, N))).astype(np.int8)
+        d, o = host(sim.step(torch.from_numpy(acts).cuda())), ob.step(acts)
+        bad = parity.compare(d, o, tol64=1e-9, tol32=2e-5, where=f"t{t} ")
+        assert bad == [], "\n".join(bad[:8])
+        parity.sync_oracle_from_device(ob, sim)
+    sim.close()
+    assert d["dist"].max() > 30.0
