@@ -7,6 +7,8 @@ R=${1:-r02}
 python -m pytest tests -m gpu -x -q > gpurun_out/t_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/t_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py > gpurun_out/${R}_bench_c4.json 2> gpurun_out/bench_c4.err; echo "bench c4 rc=$?"
+python bench.py --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline > gpurun_out/${R}_bench_c4_first220.json 2> gpurun_out/bench_c4e.err; echo "bench c4 (ticks 20-220) rc=$?"
+python tools/dev_feature_cost.py > gpurun_out/${R}_feature_cost.txt 2>&1; echo "feature cost rc=$?"
 for c in c2 c3 c5; do python bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/${R}_bench_$c.json 2> gpurun_out/bench_$c.err; echo "bench $c rc=$?"; done
 rm -rf gpurun_out/prof_final gpurun_out/prof_serial gpurun_out/pmc_fetch gpurun_out/pmc_write
 cd /tmp
