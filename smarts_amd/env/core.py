@@ -189,7 +189,7 @@ class BatchCore:
             self.cm.lane_ids, road_ids, vehicle_names, waypoints=self.cfg.waypoints, neighbors=self.cfg.neighbors,
             accelerometer=self.cfg.accelerometer, ogm=first.ogm or None, dagm=first.drivable_area_grid_map or None,
             lidar_rays=base_rays(first.lidar.sensor_params) if first.lidar else None, dt=dt, vias=self.vias,
-            road_waypoints=bool(first.road_waypoints))
+            road_waypoints=bool(first.road_waypoints), missions=self.missions)
         self._was_reset = False
         self._destroyed = False
 

@@ -223,12 +223,31 @@ class EndlessMission:
     route_roads: Tuple[str, ...] = ()
 
 
+@dataclass(frozen=True)
+class PositionalGoal:
+    """plan.py:86-120."""
+
+    position: Tuple[float, float]
+    radius: float
+
+
+@dataclass(frozen=True)
+class FixedRouteMission:
+    """plan.py:196-222 for a mission with a route: what ``EgoVehicleObservation.mission`` shows of it."""
+
+    start_position: Tuple[float, float]
+    start_heading: float
+    goal: PositionalGoal
+    route_roads: Tuple[str, ...]
+    start_time: float = 0.1
+
+
 class ObservationBuilder:
     """Dense rows (host numpy, one env) -> reference ``Observation`` objects."""
 
     def __init__(self, lane_ids: Sequence[str], lane_road_ids: Sequence[str], agent_ids: Sequence[str], *,
                  waypoints: bool, neighbors: bool, accelerometer: bool, ogm=None, lidar_rays: Optional[np.ndarray] = None,
-                 dt: float = 0.1, vias=None, dagm=None, road_waypoints: bool = False):
+                 dt: float = 0.1, vias=None, dagm=None, road_waypoints: bool = False, missions=None):
         self.lane_ids = list(lane_ids)
         self.lane_road_ids = list(lane_road_ids)
         self.agent_ids = list(agent_ids)
@@ -236,6 +255,10 @@ class ObservationBuilder:
         self.ogm, self.lidar_rays, self.dt = ogm, lidar_rays, dt
         self.dagm = dagm
         self.road_waypoints = road_waypoints
+        # per vehicle slot: smarts_amd.missions.PlannedMission | None
+        self.missions = [
+            FixedRouteMission(tuple(m.start_position), float(m.start_heading), PositionalGoal(tuple(m.goal[:2]), float(m.goal[2])),
+                              tuple(m.route_roads)) if m is not None else None for m in (missions or [])]
         self.vias = vias  # per vehicle slot: resolved mission vias (smarts_amd.vias.ResolvedVia)
 
     def vehicle_id(self, slot: int) -> str:
@@ -265,7 +288,7 @@ class ObservationBuilder:
             steering=float(f[E["STEERING"]]),
             yaw_rate=float(f[E["YAW_RATE"]]),
             road_id=road_id, lane_id=lane_id, lane_index=lane_index,
-            mission=EndlessMission(),
+            mission=(self.missions[slot] if slot < len(self.missions) and self.missions[slot] is not None else EndlessMission()),
             linear_velocity=v3("LIN_VEL"), angular_velocity=v3("ANG_VEL"),
             linear_acceleration=v3("LIN_ACC") if acc else None,
             angular_acceleration=v3("ANG_ACC") if acc else None,

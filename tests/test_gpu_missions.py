@@ -195,6 +195,8 @@ def test_hiway_env_mission_ends_at_its_goal():
                    missions=missions)
     obs = env.reset()
     ego = obs["A"].ego_vehicle_state
+    assert ego.mission.goal.position == (169.4, 68.4) and ego.mission.goal.radius == 2.0 and ego.mission.route_roads[-1] == "edge-east-WE"
+    assert obs["B"].ego_vehicle_state.mission.goal == "EndlessGoal"  # no mission given: endless, empty route
     # Pose.from_front_bumper: the centre is half a chassis length behind the start point, eastbound
     assert np.allclose(ego.position[:2], (80.0 - 1.84, 68.4), atol=1e-9) and abs(float(ego.heading) + np.pi / 2) < 1e-6  # float32 row
     route_roads = {"edge-west-WE", ":junction-intersection_13", "edge-east-WE"}
