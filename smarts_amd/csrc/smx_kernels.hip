@@ -2630,6 +2630,13 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+// orders a wavefront's own LDS traffic for the compiler (the hardware keeps a wavefront's LDS operations in order)
+#define SMX_WAVE_SYNC()                                   \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
   extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][H * W]
   __shared__ OgmPose pose[SMX_BLOCK];
@@ -2660,12 +2667,15 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
                                      // every side); the pixel test itself keeps the oracle's arithmetic
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
   const int rounds = (n_veh + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
-  for (int it = 0; it < rounds; ++it) {  // the same trip count in every wavefront: barriers inside are legal
+  // Each wavefront owns its tile and its mate list: inside the loop only lanes of ONE wavefront exchange data
+  // through LDS, whose operations a wavefront issues in order — a scheduling fence is all that is needed (four
+  // workgroup barriers per round made the four wavefronts wait for the slowest one's rectangles: 32 per env)
+  for (int it = 0; it < rounds; ++it) {
     const int obs = it * SMX_OGM_WAVES + wave;
     const bool live = obs < n_veh && pose[obs < n_veh ? obs : 0].observes;
     if (live)
       for (int k = lane; k < bytes / 16; k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
-    __syncthreads();
+    SMX_WAVE_SYNC();
     unsigned long long todo = 0ull;
     if (live) {
       const OgmPose e = pose[obs];
@@ -2703,7 +2713,7 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
       }
       todo = __ballot(in_view);
     }
-    __syncthreads();
+    SMX_WAVE_SYNC();
     while (todo != 0ull) {  // uniform in the wavefront
       const OgmMate q = mates[wave][__ffsll((long long)todo) - 1];
       todo &= todo - 1ull;
@@ -2721,12 +2731,12 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
         }
       }
     }
-    __syncthreads();
+    SMX_WAVE_SYNC();
     if (live) {
       int4* dst = reinterpret_cast<int4*>(a.out.ogm + ((size_t)env * n_veh + obs) * (size_t)bytes);
       for (int k = lane; k < bytes / 16; k += 64) dst[k] = reinterpret_cast<const int4*>(tile)[k];
     }
-    __syncthreads();  // the tile and the mate list are reused
+    SMX_WAVE_SYNC();  // the tile and the mate list are reused
   }
 }
 
