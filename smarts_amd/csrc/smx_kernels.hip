@@ -2637,10 +2637,17 @@ struct OgmPose {
     __builtin_amdgcn_wave_barrier();                      \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+// a double of another lane of the wavefront (lane index uniform): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
   extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][H * W]
   __shared__ OgmPose pose[SMX_BLOCK];
-  __shared__ OgmMate mates[SMX_OGM_WAVES][SMX_BLOCK];
   const smx_config& c = a.cfg;
   const int n_veh = c.num_vehicles;
   const size_t total = (size_t)c.num_envs * n_veh;
@@ -2676,7 +2683,11 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
     if (live)
       for (int k = lane; k < bytes / 16; k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
     SMX_WAVE_SYNC();
+    // the footprint of vehicle `lane` in this observer's frame stays in lane `lane`'s registers; the wavefront
+    // takes the vehicles in view one by one and reads each one's record with v_readlane (no LDS copy of it:
+    // 16 KB less LDS per workgroup, so that more of them fit beside the other kernels of the tick)
     unsigned long long todo = 0ull;
+    OgmMate mine = OgmMate{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0};
     if (live) {
       const OgmPose e = pose[obs];
       const double rx = e.ch, ry = e.sh;    // ego right axis
@@ -2698,25 +2709,35 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
         r1 = min(r1, H - 1);
         if (c0 <= c1 && r0 <= r1) {
           in_view = true;
-          OgmMate& q = mates[wave][lane];
-          q.cx = cx;
-          q.cy = cy;
-          q.vfx = vfx;
-          q.vfy = vfy;
-          q.vrx = vrx;
-          q.vry = vry;
-          q.c0 = c0;
-          q.r0 = r0;
-          q.bw = c1 - c0 + 1;
-          q.n_px = r1 - r0 + 1;  // (here: the rectangle's height)
+          mine.cx = cx;
+          mine.cy = cy;
+          mine.vfx = vfx;
+          mine.vfy = vfy;
+          mine.vrx = vrx;
+          mine.vry = vry;
+          mine.c0 = c0;
+          mine.r0 = r0;
+          mine.bw = c1 - c0 + 1;
+          mine.n_px = r1 - r0 + 1;  // (here: the rectangle's height)
         }
       }
       todo = __ballot(in_view);
     }
     SMX_WAVE_SYNC();
     while (todo != 0ull) {  // uniform in the wavefront
-      const OgmMate q = mates[wave][__ffsll((long long)todo) - 1];
+      const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
+      OgmMate q;
+      q.cx = readlane_f64(mine.cx, src);
+      q.cy = readlane_f64(mine.cy, src);
+      q.vfx = readlane_f64(mine.vfx, src);
+      q.vfy = readlane_f64(mine.vfy, src);
+      q.vrx = readlane_f64(mine.vrx, src);
+      q.vry = readlane_f64(mine.vry, src);
+      q.c0 = __builtin_amdgcn_readlane(mine.c0, src);
+      q.r0 = __builtin_amdgcn_readlane(mine.r0, src);
+      q.bw = __builtin_amdgcn_readlane(mine.bw, src);
+      q.n_px = __builtin_amdgcn_readlane(mine.n_px, src);
       // the rectangle in 8 x 8 pixel blocks, lane = (row, column) inside a block: no division by its width
       const int bh = q.n_px;
       const int lr = lane >> 3, lc = lane & 7;
