@@ -3985,13 +3985,20 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     if (!small_batch) {
       // the scan's halves as two launches, on two streams when forked: path seeds (-> waypoint kernels) on the
       // caller's, road facts (-> observe) on side 1
-      if (fork) (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
       const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
-      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
       if (routed)
         hipLaunchKernelGGL((k_scan_half<1, true>), dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
       else
         hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      // the facts half (-> observe) has slack, the seeds half heads the tick's longest chain (-> walk -> rows): the
+      // facts half starts when the seeds half is done and then fills the chip beside the waypoint kernels, whose two
+      // wavefronts per SIMD leave it half empty (C4, ticks 20-220: 0.815 -> 0.792 ms)
+      if (fork) {
+        (void)hipEventRecord(h->ev_fork, stream);
+        (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
+      }
+      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
+      // (holding the grid kernels back as well was slower: 0.81 -> 0.85 ms; they overlap the seeds half)
     } else if (scan_split) {
       if (routed)
         hipLaunchKernelGGL((k_scan<true, true>), dim3(scan_blocks), dim3(SMX_BLOCK), 0, stream, k);
