@@ -3189,10 +3189,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_grid_first(const KernelArgs a) {
 }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_tables(const KernelArgs a) { waypoints_tables_role(a, (int)blockIdx.x); }
-#ifndef SMX_OBSERVE_WAVES
-#define SMX_OBSERVE_WAVES 1
-#endif
-__global__ void __attribute__((amdgpu_waves_per_eu(SMX_OBSERVE_WAVES, 8))) __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
+// (capped at 168 registers for a third wavefront per SIMD beside the waypoint kernels it spills 52 of them: 0.796 -> 0.806 ms)
+__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
 
 // =================================================================================
