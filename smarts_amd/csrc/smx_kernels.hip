@@ -3018,7 +3018,7 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
     if (gid < g1) waypoints_for<SMX_FIRST_BLOCK>(a, gid, knot_scratch + threadIdx.x);
   }
   observe_role(a, block);
-  if (c.sensors & SMX_SENSOR_LIDAR)
+  if ((c.sensors & SMX_SENSOR_LIDAR) && a.lidar_blocks != 0)  // (0: the reset pass launched k_lidar for the new vehicles)
     for (size_t gid = g0; gid < g1; ++gid) {
       lidar_role(a, (int)gid);
       __syncthreads();  // the role's LDS block is reused by the next vehicle
@@ -3192,6 +3192,26 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_tables(const KernelArgs
 // (capped at 168 registers for a third wavefront per SIMD beside the waypoint kernels it spills 52 of them: 0.796 -> 0.806 ms)
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
+// The lidar of the reset pass on large batches: almost no vehicle is new in a given tick, and when an env restarts
+// all its vehicles are — neighbours in memory.  Workgroup w looks at the vehicles v = w (mod gridDim.x), 64 flags per
+// load and ballot, and runs the lidar role for the new ones it finds: an env's 64 new vehicles land in 64 different
+// workgroups instead of one after the other in k_first's, and a tick without restarts pays a few microseconds.
+#define SMX_LIDAR_FIRST_BLOCKS 1024
+__global__ void __launch_bounds__(SMX_BLOCK) k_lidar_first(const KernelArgs a) {
+  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  const size_t stride = (size_t)gridDim.x;
+  for (size_t base = blockIdx.x; base < total; base += stride * SMX_BLOCK) {
+    const size_t v = base + (size_t)threadIdx.x * stride;
+    const int f = v < total ? a.st.flags[v] : 0;
+    unsigned long long fresh = __ballot((f & SMX_F_ALIVE) && (f & SMX_F_FIRST) && !(f & SMX_F_SOCIAL));
+    while (fresh != 0ull) {  // uniform in the (one-wavefront) workgroup
+      const int l = __ffsll((long long)fresh) - 1;
+      fresh &= fresh - 1ull;
+      lidar_role(a, (int)(base + (size_t)l * stride));
+      __syncthreads();  // the role's LDS block is reused
+    }
+  }
+}
 
 // =================================================================================
 // k_reset: SMARTS.reset (smarts.py:365-460) for the selected envs — vehicles re-created at their
@@ -4117,6 +4137,13 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     if (c.sensors & SMX_SENSOR_ROAD_WAYPOINTS)  // before k_first clears SMX_F_FIRST
       hipLaunchKernelGGL(k_road_waypoints, dim3((unsigned)((total * SMX_RW_LANE_CAP + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0,
                          stream, r);
+    if (lidar_blocks && !small_batch) {
+      // large batches: the new vehicles' lidar as a launch of its own instead of one after the other inside
+      // k_first — at C5 an env restart brings 64 new vehicles, whose serial lidar roles made the reset pass 0.58 ms
+      // of a 1.5 ms tick late in a run (many restarts per tick)
+      hipLaunchKernelGGL(k_lidar_first, dim3((unsigned)std::min<size_t>(SMX_LIDAR_FIRST_BLOCKS, total)), dim3(SMX_BLOCK), 0, stream, r);
+      r.lidar_blocks = 0;
+    }
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());
