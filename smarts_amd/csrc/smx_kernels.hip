@@ -69,11 +69,21 @@ struct KernelArgs {
   double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
   KnotLists knots;          // library-owned hand-off: k_wp_walk -> k_waypoints_tables
   MissionsDev missions;     // device copy of smx_set_missions (null pointers: every mission endless)
+  // large batches: the tick's alive vehicles, compacted by k_alive_list at the start of the tick (null: launch
+  // index = vehicle).  The per-vehicle team kernels then run over full wavefronts however many agents are gone.
+  const int32_t* alive_list;
+  const int32_t* alive_count;
   int32_t* status;          // library-owned device word of SMX_DEVICE_* bits, read and cleared by smx_sync
 };
 enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 was met (and treated as "no action")
 
 #define SF(field) a.st.f64[(size_t)(field) * total + gid]
+
+// The vehicle that team (or lane) i of a per-vehicle launch works on; `total` = none (i is past the last one).
+__device__ __forceinline__ size_t launch_vehicle(const KernelArgs& a, size_t i, size_t total) {
+  if (a.alive_list == nullptr) return i < total ? i : total;
+  return i < (size_t)*a.alive_count ? (size_t)a.alive_list[i] : total;
+}
 
 // Developer timing switches ("switch a piece off and see what the tick costs without it"): they exist
 // only in the -DSMX_DEBUG_TIMING variant of the library (smarts_amd/build.py --prof); in the shipped
@@ -568,7 +578,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a,
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
-  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES;
+  const size_t gid = launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, total);
   if (gid >= total) return;  // whole teams leave together
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL)) return;
@@ -1105,7 +1115,7 @@ template <int ROLE, bool ROUTED = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_half(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM_LARGE;
+  const size_t gid = launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM_LARGE, total);
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
@@ -1557,6 +1567,23 @@ __device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const Map
   *trip_has_wp_p = trip_has_wp ? 1 : 0;  // the flags word itself is not written here (the observe role owns it)
 }
 
+// k_alive_list: the alive vehicles of the tick, compacted (large batches).  Late in an episode most agents of an env
+// are gone while the env waits for its last one (hiway_env.py:258-261): a per-vehicle team kernel then runs its
+// wavefronts a quarter to a half full.  Order within the list is that of the atomics (it varies from run to run;
+// every result is indexed by vehicle, never by list position).  The counter of the next tick is zeroed here.
+__global__ void __launch_bounds__(SMX_BLOCK) k_alive_list(const KernelArgs a, int32_t* list, int32_t* count, int32_t* count_next) {
+  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  const bool alive = gid < total && (a.st.flags[gid] & SMX_F_ALIVE);
+  const unsigned long long mask = __ballot(alive);
+  if (gid == 0) *count_next = 0;
+  if (mask == 0ull) return;
+  int base = 0;
+  if (threadIdx.x == (unsigned)(__ffsll((long long)mask) - 1)) base = atomicAdd(count, __popcll(mask));
+  base = __shfl(base, __ffsll((long long)mask) - 1);
+  if (alive) list[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (int32_t)gid;
+}
+
 // k_wp_walk: the chain walks of the waypoints sensor, one lane per (vehicle, seed lane) and nothing else —
 // no LDS, few registers, so that many wavefronts per SIMD hide the dependent loads.  Leaves the knot list of
 // the seed lane's first path and the number of paths that start there (KnotLists).
@@ -1565,10 +1592,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const size_t paths = total * SMX_WP_LANES;
-  const size_t path = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
-  if (path >= paths) return;
-  const size_t gid = path / SMX_WP_LANES;
-  const int p0 = (int)(path % SMX_WP_LANES);
+  const size_t lane_no = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  const size_t gid = launch_vehicle(a, lane_no / SMX_WP_LANES, total);
+  if (gid >= total) return;
+  const int p0 = (int)(lane_no % SMX_WP_LANES);
+  const size_t path = gid * SMX_WP_LANES + p0;
   const int flags = a.st.flags[gid];
   int n = 0, nk = 0, cnt = 0;
   double D = 0.0;
@@ -1953,6 +1981,9 @@ __device__ __forceinline__ void respawn_vehicle(const KernelArgs& a, size_t gid,
     fl |= SMX_F_SOCIAL;
   }
   a.st.flags[gid] = fl;
+  // the slot's knot lists belong to the vehicle that is gone (k_wp_walk only visits alive vehicles)
+  if (a.knots.key != nullptr)
+    for (int p = 0; p < SMX_WP_LANES; ++p) a.knots.key[gid * SMX_WP_LANES + p] = -1;
   a.st.facts_i32[(size_t)SMX_FI_TRIP_HAS_WP * total + gid] = 0;
   a.st.steps[gid] = 1;  // SensorState.step runs in the tick that creates the vehicle (agent_manager.py:250-258)
 }
@@ -3270,6 +3301,8 @@ struct smx_handle_s {
   void* map_blob;  // one device allocation holding every table
   size_t map_bytes;
   void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
+  int32_t* alive_blob;  // [total] alive list + two counters (ticks alternate), large batches
+  int alive_parity;
   KnotLists knots;
   void* ctrl_blob;   // CtrlHandoff of the two-launch controller (k_control_paths -> k_control_law)
   CtrlHandoff ctrl;
@@ -3360,6 +3393,8 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->map_blob = nullptr;
   h->map_bytes = 0;
   h->knots_blob = nullptr;
+  h->alive_blob = nullptr;
+  h->alive_parity = 0;
   h->knots = KnotLists{};
   h->ctrl_blob = nullptr;
   h->ctrl = CtrlHandoff{nullptr, nullptr};
@@ -3574,6 +3609,11 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   PTR(sg_off, int32_t);
   PTR(sg_rec, smx_seg_rec);
 #undef PTR
+  if (!h->alive_blob) {  // the tick's alive list (large batches) + its two counters
+    const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_vehicles + 2;
+    SMX_HIP(hipMalloc((void**)&h->alive_blob, n * sizeof(int32_t)));
+    SMX_HIP(hipMemset(h->alive_blob, 0, n * sizeof(int32_t)));
+  }
   // hand-off storage of the waypoints sensor's chain walks (the library's own: it never leaves the tick)
   if ((h->cfg.sensors & SMX_SENSOR_WAYPOINTS) && !h->knots_blob) {
     const size_t paths = (size_t)h->cfg.num_envs * h->cfg.num_vehicles * SMX_WP_LANES;
@@ -3923,6 +3963,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.debug_skip = h->debug_skip;
   a.knots = h->knots;
   a.status = h->status_dev;
+  a.alive_list = nullptr;
+  a.alive_count = nullptr;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
   // Small batches are bound by one wavefront's latency, so independent work is spread over more
@@ -4069,6 +4111,14 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   if (is_step && c.num_social > 0 && c.social_model == SMX_SOCIAL_IDM)
     hipLaunchKernelGGL(k_social, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a);
   const bool two_launch_control = is_step && !small_batch && h->ctrl_blob;
+  if (is_step && !small_batch && h->alive_blob) {
+    int32_t* counters = h->alive_blob + total;
+    hipLaunchKernelGGL(k_alive_list, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, h->alive_blob, counters + h->alive_parity,
+                       counters + (h->alive_parity ^ 1));
+    a.alive_list = h->alive_blob;
+    a.alive_count = counters + h->alive_parity;
+    h->alive_parity ^= 1;
+  }
   if (two_launch_control) {
     // large batches: candidate paths by teams of four, then law + physics with one lane per vehicle
     const CtrlHandoff ho = h->ctrl;
@@ -4123,6 +4173,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   }
   if (!is_step || c.auto_reset) {
     KernelArgs r = a;
+    r.alive_list = nullptr;
+    r.alive_count = nullptr;
     r.first_only = 1;
     r.keep_reward_done = is_step ? 1 : 0;
     r.reset_all = (!is_step && mask == nullptr) ? 1 : 0;
@@ -4251,6 +4303,7 @@ extern "C" void smx_destroy(smx_handle h) {
   if (!h) return;
   if (h->map_blob) (void)hipFree(h->map_blob);
   if (h->knots_blob) (void)hipFree(h->knots_blob);
+  if (h->alive_blob) (void)hipFree(h->alive_blob);
   if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
   if (h->status_dev) (void)hipFree(h->status_dev);
   if (h->side_ready) {
