@@ -1457,6 +1457,7 @@ struct WpRowBook {  // which table column feeds which output row of the workgrou
   unsigned char count[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];  // wp_count of the row
   unsigned char paths[SMX_WPT_VEHICLES];                     // total number of paths of the vehicle
   unsigned char tabled[SMX_WPT_VEHICLES];                    // the vehicle's counts come from this book
+  unsigned int veh[SMX_WPT_VEHICLES];                        // the vehicle of team v (launch_vehicle: the alive list)
 };
 
 // Every path of the vehicle the long way (lanes by index, branches depth-first): every team lane walks
@@ -1678,8 +1679,9 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int P = c.wp_paths, W = c.wp_len, lookahead = c.wp_lookahead;
   const int p0 = threadIdx.x % SMX_WP_LANES, v = threadIdx.x / SMX_WP_LANES;
-  const size_t gid0 = (size_t)block * SMX_WPT_VEHICLES;
-  const size_t gid = gid0 + v;
+  // team v works on the v-th vehicle of the workgroup's sixteen launch slots (alive vehicles only when the tick
+  // has its list): the rows of a vehicle are contiguous in the outputs, the vehicles of a workgroup need not be
+  const size_t gid = launch_vehicle(a, (size_t)block * SMX_WPT_VEHICLES + v, total);
   const size_t path = gid * SMX_WP_LANES + p0, paths = total * SMX_WP_LANES;
   const int col = threadIdx.x;
   SMX_TSTAMP(tw0);
@@ -1720,6 +1722,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   const bool listed = nk <= SMX_WPK_CAP;                      // ... from a complete knot list
   const bool my_row = staged && prov < P;                     // ... that one of the kept rows holds
   if (p0 == 0) {
+    book.veh[v] = (unsigned int)(gid < total ? gid : 0);
     book.tabled[v] = (live && !serial_team) ? 1 : 0;
     book.paths[v] = (unsigned char)(seeded ? n_paths_staged : 0);
   }
@@ -1769,7 +1772,6 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
     }
   }
   const int elems = SMX_WPT_VEHICLES * P * W;
-  const size_t q0 = gid0 * (size_t)P * W;
   double gx = 0.0, gy = 0.0, gh = 0.0;  // first waypoint of this lane's path
   {
     double2* stage = reinterpret_cast<double2*>(stage_raw);
@@ -1786,22 +1788,29 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
     SMX_TSTAMP(tw2);
     SMX_TACC(1, tw1, tw2);
     int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per round
+    int vv = row / P, slot = row - vv * P;                 // row = vv * P + slot: team vv's path row `slot`
     const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
     for (int e = threadIdx.x; e < elems; e += SMX_BLOCK) {
       const int src = book.src[row];
       if (src != SMX_ROW_SKIP) {
         double2 xy = make_double2(0.0, 0.0);
         if (src >= 0 && i < (int)book.count[row]) xy = stage[i * SMX_BLOCK + src];
-        double* dst = o.wp_pos + (q0 + e) * 3;
+        double* dst = o.wp_pos + (((size_t)book.veh[vv] * P + slot) * W + i) * 3;
         dst[0] = xy.x;
         dst[1] = xy.y;
         dst[2] = 0.0;
       }
       row += drow;
+      slot += drow;
       i += di;
       if (i >= W) {
         i -= W;
         ++row;
+        ++slot;
+      }
+      while (slot >= P) {
+        slot -= P;
+        ++vv;
       }
     }
     __syncthreads();  // the stage is reused
@@ -1835,6 +1844,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
     SMX_TSTAMP(tw3b);
     SMX_TACC(25, tw3, tw3b);
     int row = threadIdx.x / W, i = threadIdx.x - row * W;
+    int vv = row / P, slot = row - vv * P;
     const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
     for (int e = threadIdx.x; e < elems; e += SMX_BLOCK) {
       const int src = book.src[row];
@@ -1846,7 +1856,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
         cell.lane = -1;
         cell.lane_index = 0;
         if (src >= 0 && i < (int)book.count[row]) cell = stage[i * SMX_BLOCK + src];
-        const size_t q = q0 + e;
+        const size_t q = ((size_t)book.veh[vv] * P + slot) * W + i;
         o.wp_heading[q] = cell.heading;
         o.wp_lane_width[q] = cell.width;
         o.wp_speed_limit[q] = cell.speed;
@@ -1854,10 +1864,16 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
         o.wp_lane_index[q] = cell.lane_index;
       }
       row += drow;
+      slot += drow;
       i += di;
       if (i >= W) {
         i -= W;
         ++row;
+        ++slot;
+      }
+      while (slot >= P) {
+        slot -= P;
+        ++vv;
       }
     }
     // wp_count: [vehicle][0] = number of paths, [1 + slot] = waypoints kept of the path in that row
@@ -1865,7 +1881,7 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
     for (int e = threadIdx.x; e < cells; e += SMX_BLOCK) {
       const int vv = e / (P + 1), qq = e - vv * (P + 1);
       if (!book.tabled[vv]) continue;
-      o.wp_count[gid0 * (size_t)(P + 1) + e] = qq == 0 ? book.paths[vv] : book.count[vv * P + qq - 1];
+      o.wp_count[(size_t)book.veh[vv] * (P + 1) + qq] = qq == 0 ? book.paths[vv] : book.count[vv * P + qq - 1];
     }
     SMX_TSTAMP(tw3c);
     SMX_TACC(26, tw3b, tw3c);
