@@ -2695,6 +2695,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
   extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][H * W]
   __shared__ OgmPose pose[SMX_BLOCK];
+  __shared__ unsigned char observers[SMX_BLOCK];  // the env's observing slots, compacted: the wavefronts share them evenly
+  __shared__ int n_observers;                     // however many agents of the env are gone
   const smx_config& c = a.cfg;
   const int n_veh = c.num_vehicles;
   const size_t total = (size_t)c.num_envs * n_veh;
@@ -2714,19 +2716,26 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
     p.sh = sin(h);
     pose[threadIdx.x] = p;
   }
+  if (wave == 0) {  // (n_veh <= 64: the first wavefront sees every slot)
+    const bool obs_here = lane < n_veh && pose[lane].observes;
+    const unsigned long long om = __ballot(obs_here);
+    if (obs_here) observers[__popcll(om & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+    if (lane == 0) n_observers = __popcll(om);
+  }
   __syncthreads();
   unsigned char* tile = tiles + (size_t)wave * bytes;
   const double res = c.ogm_resolution;
   const double inv_res = 1.0 / res;  // for the pixel RECTANGLES only (an enumeration bound with a pixel of margin on
                                      // every side); the pixel test itself keeps the oracle's arithmetic
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
-  const int rounds = (n_veh + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
+  const int rounds = (n_observers + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
   // Each wavefront owns its tile and its mate list: inside the loop only lanes of ONE wavefront exchange data
   // through LDS, whose operations a wavefront issues in order — a scheduling fence is all that is needed (four
   // workgroup barriers per round made the four wavefronts wait for the slowest one's rectangles: 32 per env)
   for (int it = 0; it < rounds; ++it) {
-    const int obs = it * SMX_OGM_WAVES + wave;
-    const bool live = obs < n_veh && pose[obs < n_veh ? obs : 0].observes;
+    const int turn = it * SMX_OGM_WAVES + wave;
+    const bool live = turn < n_observers;
+    const int obs = live ? (int)observers[turn] : 0;
     if (live)
       for (int k = lane; k < bytes / 16; k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
     SMX_WAVE_SYNC();
