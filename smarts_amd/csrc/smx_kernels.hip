@@ -1572,17 +1572,30 @@ __device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const Map
 // are gone while the env waits for its last one (hiway_env.py:258-261): a per-vehicle team kernel then runs its
 // wavefronts a quarter to a half full.  Order within the list is that of the atomics (it varies from run to run;
 // every result is indexed by vehicle, never by list position).  The counter of the next tick is zeroed here.
-__global__ void __launch_bounds__(SMX_BLOCK) k_alive_list(const KernelArgs a, int32_t* list, int32_t* count, int32_t* count_next) {
+#define SMX_ALIVE_BLOCK 1024
+__global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs a, int32_t* list, int32_t* count, int32_t* count_next) {
+  // one atomic per workgroup of 1024 (a wavefront each was 2 048 atomics on one counter: 28 us at 131 k vehicles)
+  __shared__ int wave_base[SMX_ALIVE_BLOCK / 64];
+  __shared__ int group_base;
   const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
-  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  const size_t gid = (size_t)blockIdx.x * SMX_ALIVE_BLOCK + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool alive = gid < total && (a.st.flags[gid] & SMX_F_ALIVE);
   const unsigned long long mask = __ballot(alive);
   if (gid == 0) *count_next = 0;
-  if (mask == 0ull) return;
-  int base = 0;
-  if (threadIdx.x == (unsigned)(__ffsll((long long)mask) - 1)) base = atomicAdd(count, __popcll(mask));
-  base = __shfl(base, __ffsll((long long)mask) - 1);
-  if (alive) list[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (int32_t)gid;
+  if (lane == 0) wave_base[wave] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sum = 0;
+    for (int w = 0; w < SMX_ALIVE_BLOCK / 64; ++w) {
+      const int n = wave_base[w];
+      wave_base[w] = sum;
+      sum += n;
+    }
+    group_base = sum > 0 ? atomicAdd(count, sum) : 0;
+  }
+  __syncthreads();
+  if (alive) list[group_base + wave_base[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
 }
 
 // k_wp_walk: the chain walks of the waypoints sensor, one lane per (vehicle, seed lane) and nothing else —
@@ -4081,6 +4094,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       // the facts half (-> observe) has slack, the seeds half heads the tick's longest chain (-> walk -> rows): the
       // facts half starts when the seeds half is done and then fills the chip beside the waypoint kernels, whose two
       // wavefronts per SIMD leave it half empty (C4, ticks 20-220: 0.815 -> 0.792 ms)
+      // (late in a run, with 40 % of the agents alive, starting both halves together is 1.5 % faster; with 80 % alive
+      // it is 4 % slower)
       if (fork) {
         (void)hipEventRecord(h->ev_fork, stream);
         (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
@@ -4138,7 +4153,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const bool two_launch_control = is_step && !small_batch && h->ctrl_blob;
   if (is_step && !small_batch && h->alive_blob) {
     int32_t* counters = h->alive_blob + total;
-    hipLaunchKernelGGL(k_alive_list, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, h->alive_blob, counters + h->alive_parity,
+    hipLaunchKernelGGL(k_alive_list, dim3((unsigned)((total + SMX_ALIVE_BLOCK - 1) / SMX_ALIVE_BLOCK)), dim3(SMX_ALIVE_BLOCK), 0, stream, a, h->alive_blob, counters + h->alive_parity,
                        counters + (h->alive_parity ^ 1));
     a.alive_list = h->alive_blob;
     a.alive_count = counters + h->alive_parity;
