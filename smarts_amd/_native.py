@@ -140,7 +140,7 @@ EXPORTS = [
     "smx_check_buffers", "smx_set_launch_strategy",
 ]
 LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2}
-LARGE_BATCH_VEHICLES = 16384  # SMX_LAUNCH_AUTO: the LARGE form from this many vehicles on (smx_kernels.hip)
+LARGE_BATCH_VEHICLES = 16384  # SMX_LAUNCH_AUTO: the LARGE form above this many vehicles (smx_kernels.hip)
 
 _lib: Optional[C.CDLL] = None
 

@@ -19,7 +19,7 @@
 //   k_commit    1 lane / vehicle        new flags (teardown), dones["__all__"], auto-reset respawn
 //
 // followed, for envs whose episode ended under auto_reset (parallel_env.py:303-309), by k_scan /
-// k_sensors / k_commit restricted to the re-created vehicles.  From 16384 vehicles on every role is
+// k_sensors / k_commit restricted to the re-created vehicles.  Above 16384 vehicles every role is
 // launched on its own (k_waypoints, k_observe, k_lidar, k_ogm; see enqueue()).  Envs are independent
 // (reference: one process per env, parallel_env.py:96-122): no inter-workgroup communication.
 #include <hip/hip_runtime.h>
@@ -40,9 +40,10 @@
 #define SMX_COLLISION_LEEWAY 0.05  // chassis.py:75-78
 #define SMX_WP_LANES 4             // lanes of a wavefront that share one vehicle (k_control, waypoints role)
 #define SMX_POSE_SCAN_RADIUS 10.0
-// SMX_LAUNCH_AUTO: the LARGE launch form from this many vehicles on.  Measured crossover (round 2, C4's shape:
-// 8 192 vehicles 0.165 / 0.216 ms small / large, 16 384: 0.258 / 0.226, 32 768: 0.461 / 0.303, 65 536: 0.886 /
-// 0.505; C3 at 32 768: 0.514 / 0.504; C2 at 8 192: 0.133 / 0.187).
+// SMX_LAUNCH_AUTO: the LARGE launch form above this many vehicles.  Measured crossover (round 2, C4's shape:
+// 8 192 vehicles 0.165 / 0.216 ms small / large, 32 768: 0.461 / 0.303, 65 536: 0.886 / 0.505; C3 at 32 768:
+// 0.514 / 0.504; C2 at 8 192: 0.133 / 0.187).  At 16 384 the two cross: every agent alive 0.258 / 0.226, over
+// ticks 50-550 of a run (fewer alive) 0.223 / 0.250 — the longer run decides, 16 384 stays small.
 #define SMX_LARGE_BATCH_VEHICLES 16384
 #define SMX_WPT_PRELOAD 8           // knots of a path held in registers while it is interpolated
 
@@ -4010,7 +4011,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // k_sensors); large batches are bound by throughput, where the same tricks cost occupancy
   // (131 k vehicles: k_scan 0.69 vs 0.52 ms split vs back-to-back, OGM inside k_sensors +6 %).
   const bool small_batch = h->launch_strategy == SMX_LAUNCH_SMALL ||
-                           (h->launch_strategy == SMX_LAUNCH_AUTO && total < SMX_LARGE_BATCH_VEHICLES) || SMX_SKIP(*h, 131072);
+                           (h->launch_strategy == SMX_LAUNCH_AUTO && total <= SMX_LARGE_BATCH_VEHICLES) || SMX_SKIP(*h, 131072);
   const int scan_split = (small_batch || SMX_SKIP(*h, 65536)) ? 1 : 0;
   const int scan_blocks = (scan_split ? 2 : 1) * (int)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
   const int vpb = SMX_BLOCK / SMX_WP_LANES;

@@ -453,7 +453,7 @@ class BatchedSim:
     def small_form(self) -> bool:
         """Whether a tick runs in the SMALL launch form (smx_kernels.hip: SMX_LARGE_BATCH_VEHICLES)."""
         s = self.cfg.launch_strategy
-        return s == "small" or (s == "auto" and self.E * self.N < nat.LARGE_BATCH_VEHICLES)
+        return s == "small" or (s == "auto" and self.E * self.N <= nat.LARGE_BATCH_VEHICLES)
 
     def handoff_bytes_per_agent_step(self) -> int:
         """Bytes written by one kernel of the tick and read by a later one (path seeds, road facts, next flags):

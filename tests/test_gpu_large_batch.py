@@ -1,6 +1,6 @@
 """GPU parity of the LARGE launch strategy (smx_set_launch_strategy): one launch per role, k_scan's halves back
 to back, the register form of k_control, waypoint rows emitted in memory order from LDS knot tables
-(k_waypoints_tables), k_lidar / k_ogm on their own.  AUTO picks this form from 16384 vehicles on, where an oracle
+(k_waypoints_tables), k_lidar / k_ogm on their own.  AUTO picks this form above 16384 vehicles, where an oracle
 run is out of reach; forced onto oracle-sized batches here, every output is held to the oracle directly, and
 BASELINE-shaped batches above the threshold are held to small-strategy slices of themselves.
 """
@@ -116,7 +116,7 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
     ("4lane", 768, 16, 8, 10, {}),
 ])
 def test_batches_above_the_threshold_agree_with_small_slices(name, E, N, sub, ticks, extra, compiled_maps):
-    """AUTO from 16384 vehicles on = the LARGE form (below: the small form, past 8192 vehicles with the register
+    """AUTO above 16384 vehicles = the LARGE form (below: the small form, past 8192 vehicles with the register
     form of k_control).  The batch is `sub` distinct envs tiled E / sub times, so the
     first and the last slice must both equal a `sub`-env batch stepped in the small form."""
     import torch

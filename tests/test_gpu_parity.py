@@ -595,7 +595,7 @@ def test_full_size_properties(compiled_maps):
 
 
 def test_large_batch_launch_strategy_agrees_with_small_batch(compiled_maps):
-    """From 16384 vehicles on (the LARGE launch form) the scan halves, the OGM tiles and every sensor role get their own
+    """Above 16384 vehicles (the LARGE launch form) the scan halves, the OGM tiles and every sensor role get their own
     launch (smx_kernels.hip enqueue()); a 4160 x 8 batch must compute what a 32-env slice of it
     (small-batch strategy) computes."""
     import torch
