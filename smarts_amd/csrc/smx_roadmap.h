@@ -325,9 +325,7 @@ struct RouteFilter {
 // on the host: host_lane_allowed in smx_kernels.hip).
 __device__ __forceinline__ bool lane_allowed(const MapDev& m, const RouteFilter& f, int lane) {
   if (f.n == 0) return true;
-#ifndef SMX_ROUTE_RULE_ON_DEVICE
   if (f.n == SMX_ROUTE_FIXED) return m.route_lane_ok[f.road[0] * m.n_lanes + lane] != 0;
-#endif
   const int road = m.lane_road[SMX_BCHK(14, lane, m.n_lanes)];
   if (!f.has(m, road)) return false;
   if (road != f.last()) {
