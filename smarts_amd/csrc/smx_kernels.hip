@@ -46,6 +46,10 @@
 // ticks 50-550 of a run (fewer alive) 0.223 / 0.250 — the longer run decides, 16 384 stays small.
 #define SMX_LARGE_BATCH_VEHICLES 16384
 #define SMX_WPT_PRELOAD 8           // knots of a path held in registers while it is interpolated
+#define SMX_SLOW_BLOCKS 512          // workgroups of k_scan_listed (the slow list's length is only known on the device)
+#ifndef SMX_SCAN_UNSEEDED
+#define SMX_SCAN_UNSEEDED 0         // developer variant (-DSMX_SCAN_UNSEEDED=1): the scan never starts from last tick's answers
+#endif
 
 struct KernelArgs {
   smx_config cfg;
@@ -75,6 +79,12 @@ struct KernelArgs {
   const int32_t* alive_list;
   const int32_t* alive_count;
   int32_t* status;          // library-owned device word of SMX_DEVICE_* bits, read and cleared by smx_sync
+  // library-owned, kept from tick to tick: what the scan's seeded searches start from (smx_scan.h).  Null: unseeded.
+  double* seeds_carry;      // [4][E*N]: pose (x, y) the seeds half last ran at, d2 of its 10th nearest and of its nearest lanepoint (< 0: none)
+  double* facts_carry;      // [2][E*N]: pose (x, y) the facts half last ran at (its answers are facts_i32 / facts_f64)
+  // large batches: vehicles the one-lane scan kernels could not serve (k_scan_fast -> k_scan_half over this list)
+  int32_t* slow_list;
+  int32_t* slow_count;
 };
 enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 was met (and treated as "no action")
 
@@ -1015,7 +1025,19 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
       cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
     }
     const bool social = (flags & SMX_F_SOCIAL) != 0;  // only its nearest lane is ever asked for (neighbour rows)
-    RoadFacts h = team_road_facts<TEAM>(m, s.x, s.y, fmax(SMX_POSE_SCAN_RADIUS, 2.0 * m.default_lane_width), social ? 0 : 4, cx, cy);
+    FactsCarry fc;
+    fc.valid = false;
+    if (a.facts_carry != nullptr && !(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
+      fc.qx = a.facts_carry[gid];
+      fc.qy = a.facts_carry[total + gid];
+      fc.prev_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
+      fc.valid = fi[(size_t)SMX_FI_LANE * total + gid] >= 0;
+    }
+    RoadFacts h = team_road_facts_seeded<TEAM>(m, s.x, s.y, SMX_POSE_SCAN_RADIUS, social ? 0 : 4, cx, cy, fc, a.dagm_reach + 0.1);
+    if (a.facts_carry != nullptr && rank == 0) {
+      a.facts_carry[gid] = s.x;
+      a.facts_carry[total + gid] = s.y;
+    }
     SMX_TSTAMP(ts1);
     SMX_TACC(10, ts0, ts1);
     // wrong-way test input (sensors.py:556-562, 581-586): the lane heading at the point of the
@@ -1039,10 +1061,31 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   if (flags & SMX_F_SOCIAL) return;
   SMX_TSTAMP(ts3);
   Top10 t;
-  team_nearest10<TEAM>(m, s.x, s.y, t);
+  LaneGuess guess;
+  SeedsCarry scy;
+  scy.valid = false;
+  if (a.seeds_carry != nullptr && !(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
+    const int32_t* sc_ = a.st.seed_cache;
+    scy.qx = a.seeds_carry[gid];
+    scy.qy = a.seeds_carry[total + gid];
+    scy.d10 = a.seeds_carry[2 * total + gid];
+    scy.d1 = a.seeds_carry[3 * total + gid];
+    scy.prev_road = sc_[0 * total + gid];
+    scy.prev_lanes = sc_[4 * total + gid];
+#pragma unroll
+    for (int q = 0; q < SMX_SEED_LANES; ++q) scy.prev_start[q] = sc_[(size_t)(5 + q) * total + gid];
+    scy.valid = true;
+  }
+  const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
+  team_nearest10_carried<TEAM>(m, s.x, s.y, scy, t, guess);
+  if (a.seeds_carry != nullptr && rank == 0) {
+    a.seeds_carry[gid] = s.x;
+    a.seeds_carry[total + gid] = s.y;
+    a.seeds_carry[2 * total + gid] = t.idx[9] >= 0 ? t.d2[9] : -1.0;
+    a.seeds_carry[3 * total + gid] = t.idx[0] >= 0 ? t.d2[0] : -1.0;
+  }
   SMX_TSTAMP(ts4);
   SMX_TACC(12, ts3, ts4);
-  const bool wp_on = (c.sensors & SMX_SENSOR_WAYPOINTS) != 0;
   // what the controller (and the waypoints sensor) ask: paths at this pose with the agent's route
   if (SMX_SKIP(a, 4096)) return;
   Top10Scores sc;
@@ -1054,13 +1097,13 @@ __device__ __forceinline__ void scan_role(const KernelArgs& a, const MapDev& m, 
   }
   SMX_TSTAMP(ts4b);
   SMX_TACC(9, ts4, ts4b);
-  const PathSeeds seed = team_compute_path_seeds<TEAM, ROUTED>(m, s.x, s.y, s.heading, 5.0, true, t, sc, a.missions, (int)(gid % (size_t)c.num_vehicles));
+  const PathSeeds seed = team_compute_path_seeds<TEAM, ROUTED>(m, s.x, s.y, s.heading, 5.0, true, t, sc, a.missions, (int)(gid % (size_t)c.num_vehicles), &guess);
   // without the waypoints sensor the observation still takes the first waypoint of
   // waypoint_paths(pose, lookahead=1, within_radius=length) for the trip meter (sensors.py:270-275,
   // 349-351); TripMeterSensor.__init__ (sensors.py:885-898) asks the same on a new vehicle
   int obs_start = -1, trip_start = -1;
   if (!wp_on || (flags & SMX_F_FIRST)) {
-    const PathSeeds ts = team_compute_path_seeds<TEAM, false>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc, a.missions, 0);
+    const PathSeeds ts = team_compute_path_seeds<TEAM, false>(m, s.x, s.y, s.heading, SMX_CHASSIS_LENGTH, false, t, sc, a.missions, 0, &guess);
     trip_start = (ts.road >= 0) ? ts.start[0] : -1;
     obs_start = trip_start;
   }
@@ -1122,6 +1165,114 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __lau
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
   scan_role<SMX_TEAM_LARGE, ROUTED>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
+}
+
+// k_scan_fast (large batches): one half of the scan with ONE lane per vehicle (smx_scan.h facts_one_lane /
+// seeds_one_lane: searches seeded from last tick's answers, two passes over per-lane candidate lists).  A vehicle it
+// cannot serve — no usable carry, a list overflow, the in-junction rule, stacked lanes — is appended to the slow list
+// and served by k_scan_half's teams afterwards: one such vehicle would otherwise hold its whole wavefront for the
+// length of the searches from scratch.
+template <int ROLE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
+  __shared__ int cand_lds[(ROLE == 0 ? SMX_FACTS_CAND : SMX_SEEDS_CAND) * SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = launch_vehicle(a, (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x, total);
+  bool slow = false;
+  const int flags = gid < total ? a.st.flags[gid] : 0;
+  if (gid < total && (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST))) {
+    const VehState s = load_vehicle(a, gid, total);
+    int32_t* fi = a.st.facts_i32;
+    int* cand = cand_lds + threadIdx.x;
+    if (ROLE == 0) {
+      const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
+      const double cys[4] = {0.5, 0.5, -0.5, -0.5};
+      double cx[4], cy[4];
+      const double ch = cos(s.heading), sh = sin(s.heading);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double qx = s.x + cxs[q] * SMX_CHASSIS_WIDTH;
+        double qy = s.y + cys[q] * SMX_CHASSIS_LENGTH;
+        cx[q] = s.x + ch * (qx - s.x) + sh * (qy - s.y);
+        cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
+      }
+      const bool social = (flags & SMX_F_SOCIAL) != 0;
+      FactsCarry fc;
+      fc.valid = false;
+      if (!(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
+        fc.qx = a.facts_carry[gid];
+        fc.qy = a.facts_carry[total + gid];
+        fc.prev_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
+        fc.valid = fi[(size_t)SMX_FI_LANE * total + gid] >= 0;
+      }
+      RoadFacts h;
+      double lane_heading = 0.0;
+      if (facts_one_lane(m, s.x, s.y, SMX_POSE_SCAN_RADIUS, social ? 0 : 4, cx, cy, fc, a.dagm_reach + 0.1, cand, SMX_BLOCK,
+                         !social, h, lane_heading)) {
+        a.facts_carry[gid] = s.x;
+        a.facts_carry[total + gid] = s.y;
+        fi[(size_t)SMX_FI_LANE * total + gid] = h.lane;
+        fi[(size_t)SMX_FI_FLAGS * total + gid] =
+            (h.on_road ? SMX_FACT_ON_ROAD : 0) | ((h.corner_mask & 15) << SMX_FACT_CORNER_SHIFT);
+        a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid] = h.dist;
+        a.st.facts_f64[(size_t)SMX_FF_LANE_HEADING * total + gid] = lane_heading;
+      } else {
+        slow = true;
+      }
+    } else if (!(flags & SMX_F_SOCIAL)) {
+      SeedsCarry scy;
+      scy.valid = false;
+      if (!(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
+        const int32_t* sc_ = a.st.seed_cache;
+        scy.qx = a.seeds_carry[gid];
+        scy.qy = a.seeds_carry[total + gid];
+        scy.d10 = a.seeds_carry[2 * total + gid];
+        scy.d1 = a.seeds_carry[3 * total + gid];
+        scy.prev_road = sc_[0 * total + gid];
+        scy.prev_lanes = sc_[4 * total + gid];
+#pragma unroll
+        for (int q = 0; q < SMX_SEED_LANES; ++q) scy.prev_start[q] = sc_[(size_t)(5 + q) * total + gid];
+        scy.valid = true;
+      }
+      PathSeeds one;
+      double d1sq = -1.0;
+      if (seeds_one_lane(m, s.x, s.y, s.heading, 5.0, scy, cand, SMX_BLOCK, one, d1sq)) {
+        a.seeds_carry[gid] = s.x;
+        a.seeds_carry[total + gid] = s.y;
+        a.seeds_carry[2 * total + gid] = -1.0;  // (the tenth nearest was not looked for)
+        a.seeds_carry[3 * total + gid] = d1sq;
+        store_seeds(a, gid, total, one);
+        fi[(size_t)SMX_FI_TRIP_START * total + gid] = -1;  // (only a new vehicle or a batch without the waypoints
+        fi[(size_t)SMX_FI_OBS_START * total + gid] = -1;   //  sensor asks these: neither comes here)
+      } else {
+        slow = true;
+      }
+    }
+  }
+  // the wavefront's slow vehicles, appended with one atomic
+  const unsigned long long mask = __ballot(slow);
+  if (mask != 0ull) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(a.slow_count, __popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (slow) a.slow_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
+  }
+}
+
+// k_scan_half over a list whose length is only known on the device (the slow list): a fixed grid, teams striding it
+template <int ROLE, bool ROUTED = false>
+__global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_listed(const KernelArgs a) {
+  const smx_config& c = a.cfg;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int count = *a.slow_count;
+  constexpr int VPB = SMX_BLOCK / SMX_TEAM_LARGE;
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_TEAM_LARGE; i < count; i += (int)gridDim.x * VPB) {
+    const size_t gid = (size_t)a.slow_list[i];
+    const int flags = a.st.flags[gid];
+    scan_role<SMX_TEAM_LARGE, ROUTED>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
+  }
 }
 
 // =================================================================================
@@ -1574,7 +1725,8 @@ __device__ __forceinline__ void trip_meter_update(const KernelArgs& a, const Map
 // wavefronts a quarter to a half full.  Order within the list is that of the atomics (it varies from run to run;
 // every result is indexed by vehicle, never by list position).  The counter of the next tick is zeroed here.
 #define SMX_ALIVE_BLOCK 1024
-__global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs a, int32_t* list, int32_t* count, int32_t* count_next) {
+__global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs a, int32_t* list, int32_t* count, int32_t* count_next,
+                                                                  int32_t* slow_next) {
   // one atomic per workgroup of 1024 (a wavefront each was 2 048 atomics on one counter: 28 us at 131 k vehicles)
   __shared__ int wave_base[SMX_ALIVE_BLOCK / 64];
   __shared__ int group_base;
@@ -1583,7 +1735,10 @@ __global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool alive = gid < total && (a.st.flags[gid] & SMX_F_ALIVE);
   const unsigned long long mask = __ballot(alive);
-  if (gid == 0) *count_next = 0;
+  if (gid == 0) {
+    *count_next = 0;
+    slow_next[0] = slow_next[1] = 0;  // the slow lists of the next tick's one-lane scan (facts, seeds)
+  }
   if (lane == 0) wave_base[wave] = __popcll(mask);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -3341,6 +3496,8 @@ struct smx_handle_s {
   size_t map_bytes;
   void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
   int32_t* alive_blob;  // [total] alive list + two counters (ticks alternate), large batches
+  int32_t* slow_blob;   // [2][total] slow lists of the one-lane scan kernels (facts, seeds) + their 2 x 2 counters (ticks alternate)
+  double* scan_carry;   // [6][total]: seeds_carry (x, y, d10^2, d1^2) | facts_carry (x, y) of the seeded scan
   int alive_parity;
   KnotLists knots;
   void* ctrl_blob;   // CtrlHandoff of the two-launch controller (k_control_paths -> k_control_law)
@@ -3433,6 +3590,8 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->map_bytes = 0;
   h->knots_blob = nullptr;
   h->alive_blob = nullptr;
+  h->scan_carry = nullptr;
+  h->slow_blob = nullptr;
   h->alive_parity = 0;
   h->knots = KnotLists{};
   h->ctrl_blob = nullptr;
@@ -3566,7 +3725,8 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
       return fail(h, SMX_ERR_INVALID, "successor record out of range");
   }
   for (int i = 0; i < t->sg_off[sg_cells]; ++i)
-    if (t->sg_rec[i].lane < 0 || t->sg_rec[i].lane >= t->n_lanes) return fail(h, SMX_ERR_INVALID, "segment record out of range");
+    if (t->sg_rec[i].lane < 0 || t->sg_rec[i].lane >= t->n_lanes || t->sg_rec[i].v0 < 0 || t->sg_rec[i].v0 + 1 >= t->n_shape_pts)
+      return fail(h, SMX_ERR_INVALID, "segment record out of range");
   if (!t->lane_in_off || !t->lane_in_idx || !t->road_par_off || !t->road_par_idx)
     return fail(h, SMX_ERR_INVALID, "map tables: lane_in_* / road_par_* missing");
   for (int i = 0; i < t->lane_in_off[nl]; ++i)
@@ -3652,6 +3812,16 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_vehicles + 2;
     SMX_HIP(hipMalloc((void**)&h->alive_blob, n * sizeof(int32_t)));
     SMX_HIP(hipMemset(h->alive_blob, 0, n * sizeof(int32_t)));
+  }
+  if (!h->slow_blob) {
+    const size_t n = 2 * (size_t)h->cfg.num_envs * h->cfg.num_vehicles + 4;
+    SMX_HIP(hipMalloc((void**)&h->slow_blob, n * sizeof(int32_t)));
+    SMX_HIP(hipMemset(h->slow_blob, 0, n * sizeof(int32_t)));
+  }
+  if (!h->scan_carry) {  // all ones = NaN: nothing to start a seeded search from yet
+    const size_t n = 6 * (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+    SMX_HIP(hipMalloc((void**)&h->scan_carry, n * sizeof(double)));
+    SMX_HIP(hipMemset(h->scan_carry, 0xff, n * sizeof(double)));
   }
   // hand-off storage of the waypoints sensor's chain walks (the library's own: it never leaves the tick)
   if ((h->cfg.sensors & SMX_SENSOR_WAYPOINTS) && !h->knots_blob) {
@@ -4005,6 +4175,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.alive_list = nullptr;
   a.alive_count = nullptr;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  a.slow_list = nullptr;
+  a.slow_count = nullptr;
+  a.seeds_carry = h->scan_carry;
+  a.facts_carry = h->scan_carry ? h->scan_carry + 4 * total : nullptr;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
   // Small batches are bound by one wavefront's latency, so independent work is spread over more
   // workgroups (k_scan halves as separate roles: 54 vs 70 us at 8 k vehicles; the OGM role inside
@@ -4068,6 +4242,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, st_, k);
   };
   const bool routed = h->missions.route_last != nullptr;  // some slot has a fixed route: the scan instance that knows them
+  bool fast_scan = false;  // the tick of a large batch (not its reset pass): one-lane scan kernels + teams over their slow lists
+  int slow_parity = 0;
   auto observation_pass = [&](const KernelArgs& k, bool phases) {
     // Large batches, no per-kernel timing asked: the grid maps and the lidar (which read poses only) leave on
     // side stream 0 at once and overlap the scan — kernels bound by their own write stream beside one bound by
@@ -4088,7 +4264,22 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       // the scan's halves as two launches, on two streams when forked: path seeds (-> waypoint kernels) on the
       // caller's, road facts (-> observe) on side 1
       const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
-      if (routed)
+      const bool fast = fast_scan && k.alive_list != nullptr && !k.first_only && h->slow_blob && !SMX_SCAN_UNSEEDED;
+      const unsigned fast_blocks = (unsigned)((total + SMX_BLOCK - 1) / SMX_BLOCK);
+      KernelArgs kf = k, ks = k;  // facts / seeds: each half appends to its own slow list
+      if (fast) {
+        int32_t* slow_counters = h->slow_blob + 2 * total + 2 * slow_parity;
+        kf.slow_list = h->slow_blob;
+        kf.slow_count = slow_counters;
+        ks.slow_list = h->slow_blob + total;
+        ks.slow_count = slow_counters + 1;
+      }
+      // path seeds without the ten-nearest list: agents with a route object and no fixed route, waypoints sensor on
+      const bool fast_seeds = fast && !routed && (c.sensors & SMX_SENSOR_WAYPOINTS);
+      if (fast_seeds) {
+        hipLaunchKernelGGL(k_scan_fast<1>, dim3(fast_blocks), dim3(SMX_BLOCK), 0, stream, ks);
+        hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+      } else if (routed)
         hipLaunchKernelGGL((k_scan_half<1, true>), dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
       else
         hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
@@ -4105,7 +4296,11 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         (void)hipEventRecord(h->ev_fork, stream);
         (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
       }
-      hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
+      if (fast) {
+        hipLaunchKernelGGL(k_scan_fast<0>, dim3(fast_blocks), dim3(SMX_BLOCK), 0, s_obs, kf);
+        hipLaunchKernelGGL(k_scan_listed<0>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, s_obs, kf);
+      } else
+        hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
       // (holding the grid kernels back as well was slower: 0.81 -> 0.85 ms; they overlap the seeds half)
     } else if (scan_split) {
       if (routed)
@@ -4159,10 +4354,13 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const bool two_launch_control = is_step && !small_batch && h->ctrl_blob;
   if (is_step && !small_batch && h->alive_blob) {
     int32_t* counters = h->alive_blob + total;
+    int32_t* slow_counters = h->slow_blob + 2 * total;  // [parity][role]
     hipLaunchKernelGGL(k_alive_list, dim3((unsigned)((total + SMX_ALIVE_BLOCK - 1) / SMX_ALIVE_BLOCK)), dim3(SMX_ALIVE_BLOCK), 0, stream, a, h->alive_blob, counters + h->alive_parity,
-                       counters + (h->alive_parity ^ 1));
+                       counters + (h->alive_parity ^ 1), slow_counters + 2 * (h->alive_parity ^ 1));
     a.alive_list = h->alive_blob;
     a.alive_count = counters + h->alive_parity;
+    fast_scan = true;
+    slow_parity = h->alive_parity;
     h->alive_parity ^= 1;
   }
   if (two_launch_control) {
@@ -4350,6 +4548,8 @@ extern "C" void smx_destroy(smx_handle h) {
   if (h->map_blob) (void)hipFree(h->map_blob);
   if (h->knots_blob) (void)hipFree(h->knots_blob);
   if (h->alive_blob) (void)hipFree(h->alive_blob);
+  if (h->scan_carry) (void)hipFree(h->scan_carry);
+  if (h->slow_blob) (void)hipFree(h->slow_blob);
   if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
   if (h->status_dev) (void)hipFree(h->status_dev);
   if (h->side_ready) {

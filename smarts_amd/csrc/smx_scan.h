@@ -41,9 +41,15 @@ __device__ __forceinline__ int team_or(int v) {
 // ---------------------------------------------------------------------------------
 // road facts (see road_facts_scan): centre + 4 corners, one sweep, segments strided over the team
 // ---------------------------------------------------------------------------------
+// `dist_bound`: an upper bound of the nearest lane's distance known to the caller (last tick's nearest lane cannot
+// have moved farther away than the vehicle has driven), or SMX_INF: segments whose bounding box lies beyond it and
+// beyond the road_with_point thresholds are dropped before any distance is taken.  `cell_radius` (<= radius): how
+// far from the centre the grid cells are enumerated; the caller passes a value that covers `dist_bound` and every
+// segment a corner test can see (its threshold + half a vehicle diagonal), or `radius` itself.
 template <int TEAM>
 __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double py, double radius, int n_corners,
-                                            const double* cx, const double* cy) {
+                                            const double* cx, const double* cy, double dist_bound = SMX_INF,
+                                            double cell_radius = -1.0) {
   RoadFacts out;
   out.lane = -1;
   out.dist = SMX_INF;
@@ -53,10 +59,11 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
   int on_road = 0;
   const int r = team_rank<TEAM>();
   const double road_radius = fmax(5.0, 2.0 * m.default_lane_width);  // sumo_road_network.py:705
-  int cx0 = (int)floor((px - radius - m.sg_x0) / m.sg_cell);
-  int cx1 = (int)floor((px + radius - m.sg_x0) / m.sg_cell);
-  int cy0 = (int)floor((py - radius - m.sg_y0) / m.sg_cell);
-  int cy1 = (int)floor((py + radius - m.sg_y0) / m.sg_cell);
+  const double reach = (cell_radius >= 0.0 && cell_radius < radius) ? cell_radius : radius;
+  int cx0 = (int)floor((px - reach - m.sg_x0) / m.sg_cell);
+  int cx1 = (int)floor((px + reach - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((py - reach - m.sg_y0) / m.sg_cell);
+  int cy1 = (int)floor((py + reach - m.sg_y0) / m.sg_cell);
   cx0 = max(cx0, 0);
   cy0 = max(cy0, 0);
   cx1 = min(cx1, m.sg_nx - 1);
@@ -71,7 +78,7 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
           const double bx0 = fmin(s.x1, s.x2), bx1 = fmax(s.x1, s.x2), by0 = fmin(s.y1, s.y2), by1 = fmax(s.y1, s.y2);
           const double gx = fmax(fmax(bx0 - px, px - bx1), 0.0), gy2 = fmax(fmax(by0 - py, py - by1), 0.0);
           const double lb2 = gx * gx + gy2 * gy2;
-          const double keep_c = fmin(fmax(out.dist, s.thr), radius) + 1e-6;
+          const double keep_c = fmin(fmax(fmin(out.dist, dist_bound), s.thr), radius) + 1e-6;
           const double keep_q = s.thr + 2.0 + 1e-6;
           const double keep = n_corners > 0 ? fmax(keep_c, keep_q) : keep_c;
           if (lb2 > keep * keep) continue;
@@ -122,6 +129,28 @@ __device__ inline RoadFacts team_road_facts(const MapDev& m, double px, double p
   out.on_road = team_or<TEAM>(on_road) != 0;
   out.corner_mask = team_or<TEAM>(out.corner_mask);
   return out;
+}
+
+// What the facts half of the scan keeps from tick to tick for one vehicle: the pose it last ran at and the distance
+// of the nearest lane it found there (valid: there was one).
+struct FactsCarry {
+  bool valid;
+  double qx, qy, prev_dist;
+};
+
+// team_road_facts with radius = max(pose_radius, 2 x default lane width), seeded from `c`: last tick's nearest lane
+// lies at most (its distance then + the way driven since) away, which bounds the nearest distance now; the corners
+// see segments up to the widest road_with_point threshold (`thr_max`) + half a vehicle diagonal (< 2 m) away.
+template <int TEAM>
+__device__ inline RoadFacts team_road_facts_seeded(const MapDev& m, double px, double py, double pose_radius, int n_corners,
+                                                   const double* cx, const double* cy, const FactsCarry& c, double thr_max) {
+  const double radius = fmax(pose_radius, 2.0 * m.default_lane_width);
+  double dist_bound = SMX_INF, cell_radius = -1.0;
+  if (c.valid && c.qx == c.qx && c.qy == c.qy && c.prev_dist < radius) {
+    dist_bound = (c.prev_dist + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;
+    cell_radius = fmax(dist_bound, thr_max + (n_corners > 0 ? 2.0 : 0.0)) + 2e-6;
+  }
+  return team_road_facts<TEAM>(m, px, py, radius, n_corners, cx, cy, dist_bound, cell_radius);
 }
 
 // ---------------------------------------------------------------------------------
@@ -273,6 +302,191 @@ __device__ inline void team_nearest10(const MapDev& m, double px, double py, Top
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Seeded searches.  A vehicle moves less than two metres per tick, so last tick's answers bound this tick's:
+//   * the 10 lanepoints that were nearest at the previous pose q all lie within R10 = d10(q) + |p - q| of the new
+//     pose p, so the 10th nearest distance at p is at most R10 and no point beyond R10 can be one of the 10;
+//   * the lanepoint that was nearest on lane L still is a lanepoint of L: its distance to p bounds L's new nearest.
+// Every grid cell that meets the square of half width R around p is visited once, R the largest of those bounds:
+// the visit is exact (no ring certification), a handful of cells instead of the 5 x 5 block, and serves both the
+// ten-nearest query and the nearest lanepoint per lane of the road the paths started on last tick (a guess the
+// caller checks against the road this tick's ten nearest choose).  Results are those of team_nearest10 /
+// team_closest_filtered4 bit for bit: the same (d2, index) minima.
+// ---------------------------------------------------------------------------------
+#define SMX_SEEDED_SPAN 6  // cells per side the seeded visit handles (R up to ~10 m with 4 m cells); larger: unseeded search
+struct LaneGuess {
+  int road;     // the road whose lanes were tracked (-1: none)
+  int nk;       // lanes tracked (the road's first min(n_lanes, 4))
+  int idx[4];   // nearest lanepoint per tracked lane (-1 none)
+};
+
+template <int TEAM>
+__device__ inline bool team_nearest10_seeded(const MapDev& m, double px, double py, double r10, double reach, int k0, int k1,
+                                             int k2, int k3, int nkeys, Top10& res, int* lane_idx) {
+  const int K = 10;
+  int cx0 = (int)floor((px - reach - m.lpg_x0) / m.lpg_cell), cx1 = (int)floor((px + reach - m.lpg_x0) / m.lpg_cell);
+  int cy0 = (int)floor((py - reach - m.lpg_y0) / m.lpg_cell), cy1 = (int)floor((py + reach - m.lpg_y0) / m.lpg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.lpg_nx - 1);
+  cy1 = min(cy1, m.lpg_ny - 1);
+  if (cx0 > cx1 || cy0 > cy1 || cy1 - cy0 >= SMX_SEEDED_SPAN || cx1 - cx0 >= SMX_SEEDED_SPAN) return false;
+  double ld[K];
+  int li[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    ld[i] = SMX_INF;
+    li[i] = 0x7fffffff;
+  }
+  double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const double bound = r10 * r10;
+  const int rank = team_rank<TEAM>();
+  // the rows of the square are contiguous member ranges: their offsets are loaded together, then the members are
+  // taken as ONE sequence (member n of the concatenated rows), strided over the team, four loads in flight
+  int ra[SMX_SEEDED_SPAN], rn[SMX_SEEDED_SPAN];  // first member and running member count of every row
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < SMX_SEEDED_SPAN; ++i) {
+    const int y = cy0 + i;
+    const bool in = y <= cy1;
+    const int row = (in ? y : cy0) * m.lpg_nx;
+    const int va = m.lpg_off[row + cx0], vb = m.lpg_off[row + cx1 + 1];
+    ra[i] = va;
+    total += in ? vb - va : 0;
+    rn[i] = total;
+  }
+  auto member = [&](int n) {  // table index of member n of the concatenated rows
+    int k = ra[0] + n;
+#pragma unroll
+    for (int i = 1; i < SMX_SEEDED_SPAN; ++i)
+      if (n >= rn[i - 1]) k = ra[i] + (n - rn[i - 1]);
+    return k;
+  };
+  auto take = [&](const smx_pt_rec& p) {
+    const double dx = p.x - px, dy = p.y - py;
+    const double d2 = dx * dx + dy * dy;
+    if (d2 <= bound && (d2 < ld[K - 1] || (d2 == ld[K - 1] && p.idx < li[K - 1]))) {
+      double cd = d2;
+      int ci = p.idx;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool lt = (cd < ld[k]) || (cd == ld[k] && ci < li[k]);
+        const double td = lt ? ld[k] : cd;
+        const int ti = lt ? li[k] : ci;
+        ld[k] = lt ? cd : ld[k];
+        li[k] = lt ? ci : li[k];
+        cd = td;
+        ci = ti;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+      if (q < nkeys && p.lane == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+        bd[q] = d2;
+        bi[q] = p.idx;
+      }
+    }
+  };
+  for (int n0 = rank; n0 < total; n0 += 4 * TEAM) {
+    smx_pt_rec rec[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u * TEAM;
+      rec[u] = m.lpg_pts[member(n < total ? n : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (n0 + u * TEAM < total) take(rec[u]);
+  }
+  // merge the team's lists (as team_nearest10 does); one lane: the list is the result
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    double wd = ld[0];
+    int wi = li[0];
+    team_min_pair<TEAM>(wd, wi);
+    res.d2[j] = wd;
+    res.idx[j] = (wi == 0x7fffffff) ? -1 : wi;
+    const bool mine = (li[0] == wi) && (wi != 0x7fffffff);
+#pragma unroll
+    for (int k = 0; k + 1 < K; ++k) {
+      ld[k] = mine ? ld[k + 1] : ld[k];
+      li[k] = mine ? li[k + 1] : li[k];
+    }
+    if (mine) {
+      ld[K - 1] = SMX_INF;
+      li[K - 1] = 0x7fffffff;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double d = bd[q];
+    int i = bi[q];
+    if (q < nkeys) team_min_pair<TEAM>(d, i);
+    lane_idx[q] = (q < nkeys && i != 0x7fffffff) ? i : -1;
+  }
+  return res.idx[K - 1] >= 0;  // ten points were found inside the bound, as the bound promises (else: unseeded search)
+}
+
+// What the seeds half of the scan keeps from tick to tick for one vehicle.
+struct SeedsCarry {
+  bool valid;
+  double qx, qy, d10;   // pose of the last search, d2 of its 10th nearest lanepoint (< 0 or NaN: none)
+  double d1;            // d2 of its nearest lanepoint (< 0 or NaN: none)
+  int prev_road, prev_lanes, prev_start[SMX_SEED_LANES];  // last tick's path seeds (seed_cache)
+};
+
+// The ten nearest lanepoints at (px, py), seeded from `c` when it holds a usable bound, and the nearest lanepoint on
+// each lane of last tick's seed road (`guess`, road -1 when not available).
+template <int TEAM>
+__device__ inline void team_nearest10_carried(const MapDev& m, double px, double py, const SeedsCarry& c, Top10& t,
+                                              LaneGuess& guess) {
+  guess.road = -1;
+  guess.nk = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) guess.idx[q] = -1;
+  bool seeded = false;
+  if (c.valid && c.d10 >= 0.0 && c.d10 < 1.0e290 && c.qx == c.qx && c.qy == c.qy) {
+    const double r10 = (sqrt(c.d10) + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;
+    double reach = r10;
+    int k0 = -9, k1 = -9, k2 = -9, k3 = -9, nk = 0;
+    if (c.prev_road >= 0 && c.prev_lanes >= 1) {
+      nk = min(c.prev_lanes, SMX_SEED_LANES);
+      const int la = m.road_lane_off[c.prev_road];
+      k0 = m.road_lanes[la];
+      k1 = nk > 1 ? m.road_lanes[la + 1] : -9;
+      k2 = nk > 2 ? m.road_lanes[la + 2] : -9;
+      k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
+      bool all = true;
+#pragma unroll
+      for (int q = 0; q < SMX_SEED_LANES; ++q) {
+        const int st = c.prev_start[q];
+        if (q < nk) {
+          if (st >= 0) {
+            const smx_lp_rec* r = m.lp_rec + st;
+            reach = fmax(reach, euclid(px, py, r->x, r->y) * (1.0 + 1e-12) + 1e-9);
+          } else {
+            all = false;
+          }
+        }
+      }
+      if (!all) nk = 0;
+    }
+    seeded = team_nearest10_seeded<TEAM>(m, px, py, r10, reach, k0, k1, k2, k3, nk, t, guess.idx);
+    if (seeded && nk > 0) {
+      bool all = true;
+#pragma unroll
+      for (int q = 0; q < SMX_SEED_LANES; ++q) all = all && (q >= nk || guess.idx[q] >= 0);
+      if (all) {
+        guess.road = c.prev_road;
+        guess.nk = nk;
+      }
+    }
+  }
+  if (!seeded) team_nearest10<TEAM>(m, px, py, t);
+}
+
 // Nearest lanepoint per key (lane or road), up to 4 keys at once (see closest_filtered4).
 template <int TEAM>
 __device__ inline void team_closest_filtered4(const MapDev& m, double px, double py, int k0, int k1, int k2, int k3,
@@ -385,7 +599,8 @@ __device__ inline int team_closest_on_route(const MapDev& m, const RouteFilter& 
 template <int TEAM, bool ROUTED>
 __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, double py, double heading,
                                                     double within_radius, bool has_route_object, const Top10& t,
-                                                    const Top10Scores& sc, const MissionsDev& ms, int slot) {
+                                                    const Top10Scores& sc, const MissionsDev& ms, int slot,
+                                                    const LaneGuess* guess = nullptr) {
   PathSeeds s;
   s.f.none();
   s.road = -1;
@@ -441,7 +656,13 @@ __device__ inline PathSeeds team_compute_path_seeds(const MapDev& m, double px, 
               k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
     SMX_TSTAMP(tp2);
     SMX_TACC(22, tp1, tp2);
-    team_closest_filtered4<TEAM>(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
+    if (guess != nullptr && guess->road == s.road && guess->nk == nk) {
+      // the seeded visit has already found the nearest lanepoint on each of this road's lanes
+#pragma unroll
+      for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = q < nk ? guess->idx[q] : -1;
+    } else {
+      team_closest_filtered4<TEAM>(m, px, py, k0, k1, k2, k3, nk, false, s.start, nullptr);
+    }
     SMX_TSTAMP(tp3);
     SMX_TACC(23, tp2, tp3);
   }
@@ -512,7 +733,7 @@ __device__ inline void team_position_at_shape_offset(const MapDev& m, int v0, in
 // nearest-lane sweep has just measured it), or SMX_INF: segments whose bounding box lies farther cannot hold
 // the minimum and are skipped from the first one on, not only once the sweep has found a good candidate.
 template <int TEAM>
-__device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py, double dist_hint) {
+__device__ inline double team_lane_heading_at_point_linear(const MapDev& m, int lane, double px, double py, double dist_hint) {
   const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
   const int r = team_rank<TEAM>();
   // ---- offset_along_lane: a vertex that equals the point wins (first such vertex) ...
@@ -584,6 +805,448 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
   return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
 }
 
+
+// The same, with the candidate segments taken from the segment grid instead of a walk over the lane's vertices
+// (a lane of scenarios/loop has up to 49 of them).  `dist_hint` is the lane's distance as the nearest-lane sweep has
+// just measured it (another evaluation of the same quantity, so 1e-6 covers their rounding many times over): only
+// segments whose bounding box lies within it can hold the minimum of offset_along_lane — or a vertex equal to the
+// point — and every such segment is listed in a grid cell that meets the square of that half width around the
+// point.  Candidates come in cell order, so the reference's "first segment at the minimum" (a strict < in vertex
+// order) is the lexicographic minimum of (distance, vertex index); a segment listed in several cells is evaluated
+// more than once, with the same result.
+template <int TEAM>
+__device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, double px, double py, double dist_hint) {
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  const int r = team_rank<TEAM>();
+  int vertex_hit = 0x7fffffff;
+  double min_dist = SMX_INF, min_offset = -1.0;
+  int min_v = 0x7fffffff;
+  {
+    const double reach = dist_hint + 1e-6;
+    int cx0 = (int)floor((px - reach - m.sg_x0) / m.sg_cell), cx1 = (int)floor((px + reach - m.sg_x0) / m.sg_cell);
+    int cy0 = (int)floor((py - reach - m.sg_y0) / m.sg_cell), cy1 = (int)floor((py + reach - m.sg_y0) / m.sg_cell);
+    cx0 = max(cx0, 0);
+    cy0 = max(cy0, 0);
+    cx1 = min(cx1, m.sg_nx - 1);
+    cy1 = min(cy1, m.sg_ny - 1);
+    if (cx0 <= cx1) {
+      for (int gy = cy0; gy <= cy1; ++gy) {
+        const int row = gy * m.sg_nx;
+        const int ka = m.sg_off[row + cx0], kb = m.sg_off[row + cx1 + 1];
+        for (int k = ka + r; k < kb; k += TEAM) {
+          const smx_seg_rec s = m.sg_rec[k];
+          if (s.lane != lane) continue;
+          if (s.x1 == px && s.y1 == py) vertex_hit = min(vertex_hit, s.v0);
+          if (s.x2 == px && s.y2 == py) vertex_hit = min(vertex_hit, s.v0 + 1);
+          {
+            const double gx = fmax(fmax(fmin(s.x1, s.x2) - px, px - fmax(s.x1, s.x2)), 0.0);
+            const double gy2 = fmax(fmax(fmin(s.y1, s.y2) - py, py - fmax(s.y1, s.y2)), 0.0);
+            const double keep = fmin(min_dist, dist_hint) + 1e-6;
+            if (gx * gx + gy2 * gy2 > keep * keep) continue;
+          }
+          const smx_shape_rec a = m.shape_rec[s.v0];  // (x, y) = (s.x1, s.y1); its length and arclength are wanted
+          const double d = a.len;
+          const double u = ((px - s.x1) * (s.x2 - s.x1)) + ((py - s.y1) * (s.y2 - s.y1));
+          const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+          double fx, fy;
+          position_at_offset(s.x1, s.y1, s.x2, s.y2, d, poff, fx, fy);
+          const double dist = euclid(px, py, fx, fy);
+          if (dist < min_dist || (dist == min_dist && s.v0 < min_v)) {
+            min_dist = dist;
+            min_offset = poff + a.cum;
+            min_v = s.v0;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int msk = TEAM / 2; msk >= 1; msk >>= 1) vertex_hit = min(vertex_hit, __shfl_xor(vertex_hit, msk, TEAM));
+  int v_near = v0;  // the vertex the offset was measured from
+  double offset;
+  if (vertex_hit != 0x7fffffff) {
+    offset = m.shape_rec[vertex_hit].cum;
+    v_near = vertex_hit;
+  } else {
+    double bd = min_dist;
+    int bv = min_v;
+    team_min_pair<TEAM>(bd, bv);  // smallest distance, then the earliest segment
+    // a lane that holds the winning (distance, segment) pair hands its offset to the team
+    int owner = (min_dist == bd && min_v == bv) ? r : TEAM;
+#pragma unroll
+    for (int msk = TEAM / 2; msk >= 1; msk >>= 1) owner = min(owner, __shfl_xor(owner, msk, TEAM));
+    offset = __shfl(min_offset, owner < TEAM ? owner : 0, TEAM);
+    if (bv != 0x7fffffff) v_near = bv;
+  }
+  // ---- vector_at_offset
+  const double L = m.lane_length[lane];
+  double s_off, e_off;
+  if (offset >= L) {
+    s_off = L - 1.0;
+    e_off = L;
+  } else {
+    s_off = offset;
+    e_off = offset + 1.0;
+  }
+  s_off = fmax(s_off, 0.0);
+  double p1x, p1y, p2x, p2y;
+  const int vfrom = (m.shape_rec[v_near].cum <= s_off) ? v_near : v0;
+  team_position_at_shape_offset<TEAM>(m, v0, v1, s_off, p1x, p1y, vfrom);
+  team_position_at_shape_offset<TEAM>(m, v0, v1, e_off, p2x, p2y, vfrom);
+  const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
+  const double half = ang * 0.5;
+  const double qz = sin(half), qw = cos(half);
+  return wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
+}
+
+
+// ---------------------------------------------------------------------------------
+// One lane per vehicle (large batches).  With the seeded bounds a vehicle looks at a dozen grid records and needs
+// the full distance arithmetic for three to six of them; a team of lanes then mostly repeats the per-vehicle part
+// (SQ counters, round 3: 4 lanes x 4.0 k instructions against 13.5 k for one lane that walks the records and
+// evaluates on the spot — 64 vehicles of a wavefront meet their few hits at different records, so the wavefront
+// pays the evaluation at nearly every record).  The one-lane form therefore runs in two passes: pass 1 applies the
+// cheap bounding-box test to every record and keeps the survivors' indices in a per-lane list in LDS; pass 2 runs
+// the distance arithmetic down the lists, whose lengths are alike across the wavefront.  Same minima, same bits as
+// team_road_facts / team_lane_heading_at_point; lists that overflow (`false`) send the vehicle to those.
+// ---------------------------------------------------------------------------------
+#define SMX_FACTS_CAND 24  // survivors kept per vehicle (3 lanes x 1-2 segments typically)
+
+// `cand`: this lane's column of an LDS array [SMX_FACTS_CAND][stride] of record indices.
+__device__ inline bool facts_one_lane(const MapDev& m, double px, double py, double pose_radius, int n_corners,
+                                      const double* cx, const double* cy, const FactsCarry& c, double thr_max, int* cand,
+                                      int stride, bool want_heading, RoadFacts& out, double& lane_heading) {
+  const double radius = fmax(pose_radius, 2.0 * m.default_lane_width);
+  if (!(c.valid && c.qx == c.qx && c.qy == c.qy && c.prev_dist < radius)) return false;
+  const double dist_bound = (c.prev_dist + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;
+  if (!(dist_bound < radius)) return false;
+  const double reach = fmax(dist_bound, thr_max + (n_corners > 0 ? 2.0 : 0.0)) + 4e-6;
+  const double road_radius = fmax(5.0, 2.0 * m.default_lane_width);  // sumo_road_network.py:705
+  int cx0 = (int)floor((px - reach - m.sg_x0) / m.sg_cell), cx1 = (int)floor((px + reach - m.sg_x0) / m.sg_cell);
+  int cy0 = (int)floor((py - reach - m.sg_y0) / m.sg_cell), cy1 = (int)floor((py + reach - m.sg_y0) / m.sg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.sg_nx - 1);
+  cy1 = min(cy1, m.sg_ny - 1);
+  // ---- pass 1: records whose bounding box can matter to the centre (nearest lane within the bound, or its
+  // road_with_point threshold) or to a corner (threshold + half a vehicle diagonal)
+  int n = 0;
+  bool overflow = false;
+  if (cx0 <= cx1) {
+    for (int gy = cy0; gy <= cy1; ++gy) {
+      const int row = gy * m.sg_nx;
+      const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
+      for (int k = a; k < b; ++k) {
+        const smx_seg_rec* s = m.sg_rec + k;
+        const double x1 = s->x1, y1 = s->y1, x2 = s->x2, y2 = s->y2, thr = s->thr;
+        const double gx = fmax(fmax(fmin(x1, x2) - px, px - fmax(x1, x2)), 0.0);
+        const double gy2 = fmax(fmax(fmin(y1, y2) - py, py - fmax(y1, y2)), 0.0);
+        const double keep_c = fmin(fmax(dist_bound, thr), radius) + 3e-6;
+        const double keep = n_corners > 0 ? fmax(keep_c, thr + 2.0 + 1e-6) : keep_c;
+        if (gx * gx + gy2 * gy2 > keep * keep) continue;
+        if (n < SMX_FACTS_CAND)
+          cand[n * stride] = k;
+        else
+          overflow = true;
+        ++n;
+      }
+    }
+  }
+  if (overflow) return false;
+  // ---- pass 2: the distances (distance_point_to_line, math.py:393-411), as team_road_facts takes them
+  out.lane = -1;
+  out.dist = SMX_INF;
+  out.on_road = false;
+  out.corner_mask = 0;
+  int lane_key = 0x7fffffff;
+  for (int i = 0; i < n; ++i) {
+    const smx_seg_rec s = m.sg_rec[cand[i * stride]];
+    const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
+    const double d = sqrt(ex * ex + ey * ey);
+    const double dd = d * d;
+    const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
+    auto dist_to = [&](double qx, double qy) {
+      const double u = ((qx - s.x1) * sx) + ((qy - s.y1) * sy);
+      double offset;
+      if (d == 0.0 || u < 0.0 || u > dd) {
+        offset = (u < 0.0) ? 0.0 : d;
+      } else {
+        offset = u / d;
+      }
+      if (offset == 0.0) {
+        const double fx = qx - s.x1, fy = qy - s.y1;
+        return sqrt(fx * fx + fy * fy);
+      }
+      const double uu = offset / d;
+      const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
+      const double fx = qx - ix, fy = qy - iy;
+      return sqrt(fx * fx + fy * fy);
+    };
+    {
+      const double dist = dist_to(px, py);
+      if (dist < radius) {
+        if (dist < out.dist || (dist == out.dist && s.lane < lane_key)) {
+          out.dist = dist;
+          lane_key = s.lane;
+        }
+        if (dist < road_radius && dist < s.thr) out.on_road = true;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // a corner that already lies on a road has nothing more to learn
+      if (q < n_corners && !(out.corner_mask & (1 << q))) {
+        const double dist = dist_to(q == 0 ? cx[0] : (q == 1 ? cx[1] : (q == 2 ? cx[2] : cx[3])),
+                                    q == 0 ? cy[0] : (q == 1 ? cy[1] : (q == 2 ? cy[2] : cy[3])));
+        if (dist < road_radius && dist < s.thr) out.corner_mask |= (1 << q);
+      }
+    }
+  }
+  out.lane = lane_key == 0x7fffffff ? -1 : lane_key;
+  lane_heading = 0.0;
+  if (!want_heading || out.lane < 0 || m.lane_in_junction[out.lane]) return true;
+  // ---- the lane heading at the nearest point of the nearest lane (team_lane_heading_at_point): its candidate
+  // segments — bounding box within the lane's distance — are among the survivors of pass 1
+  const int lane = out.lane;
+  const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  int vertex_hit = 0x7fffffff;
+  double min_dist = SMX_INF, offset = -1.0;
+  int min_v = 0x7fffffff;
+  for (int i = 0; i < n; ++i) {
+    const smx_seg_rec s = m.sg_rec[cand[i * stride]];
+    if (s.lane != lane) continue;
+    if (s.x1 == px && s.y1 == py) vertex_hit = min(vertex_hit, s.v0);
+    if (s.x2 == px && s.y2 == py) vertex_hit = min(vertex_hit, s.v0 + 1);
+    {
+      const double gx = fmax(fmax(fmin(s.x1, s.x2) - px, px - fmax(s.x1, s.x2)), 0.0);
+      const double gy2 = fmax(fmax(fmin(s.y1, s.y2) - py, py - fmax(s.y1, s.y2)), 0.0);
+      const double keep = fmin(min_dist, out.dist) + 1e-6;
+      if (gx * gx + gy2 * gy2 > keep * keep) continue;
+    }
+    const smx_shape_rec a = m.shape_rec[s.v0];
+    const double d = a.len;
+    const double u = ((px - s.x1) * (s.x2 - s.x1)) + ((py - s.y1) * (s.y2 - s.y1));
+    const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
+    double fx, fy;
+    position_at_offset(s.x1, s.y1, s.x2, s.y2, d, poff, fx, fy);
+    const double dist = euclid(px, py, fx, fy);
+    if (dist < min_dist || (dist == min_dist && s.v0 < min_v)) {
+      min_dist = dist;
+      offset = poff + a.cum;
+      min_v = s.v0;
+    }
+  }
+  int v_near = v0;
+  if (vertex_hit != 0x7fffffff) {
+    offset = m.shape_rec[vertex_hit].cum;
+    v_near = vertex_hit;
+  } else if (min_v != 0x7fffffff) {
+    v_near = min_v;
+  }
+  const double L = m.lane_length[lane];
+  double s_off, e_off;
+  if (offset >= L) {
+    s_off = L - 1.0;
+    e_off = L;
+  } else {
+    s_off = offset;
+    e_off = offset + 1.0;
+  }
+  s_off = fmax(s_off, 0.0);
+  double p1x, p1y, p2x, p2y;
+  const int vfrom = (m.shape_rec[v_near].cum <= s_off) ? v_near : v0;
+  team_position_at_shape_offset<1>(m, v0, v1, s_off, p1x, p1y, vfrom);
+  team_position_at_shape_offset<1>(m, v0, v1, e_off, p2x, p2y, vfrom);
+  const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
+  const double half = ang * 0.5;
+  const double qz = sin(half), qw = cos(half);
+  lane_heading = wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
+  return true;
+}
+
+// ---------------------------------------------------------------------------------
+// Path seeds, one lane per vehicle (large batches), without the ten-nearest list.
+// closest_lanepoints (lanepoints.py:526-590) keeps, of the 10 nearest lanepoints, the one with the smallest
+// d2 + |heading difference| (the nearest one always eligible, the others if within the radius).  The heading term
+// is at most pi, so the winner's d2 is at most T = d2(nearest) + pi: it lies in the set C of lanepoints with
+// d2 <= T.  C is a prefix of the (d2, index) order; when it has at most ten members it is a prefix of the ten
+// nearest, every one of the ten outside it scores more than the nearest lanepoint does, and the winner over C —
+// smallest (score, d2, index), the order the reference's first-minimum scan induces — is the reference's winner.
+// With more than ten members (stacked lanes) the vehicle goes to the ten-nearest form.
+// Seeded like team_nearest10_seeded: d(nearest) now <= d(nearest) then + the way driven, which bounds T before the
+// visit; pass 1 visits the cells of that reach once (nearest lanepoint, nearest per lane of last tick's road,
+// survivors d2 <= the a-priori T into a per-lane LDS list), pass 2 scores the survivors.
+// ---------------------------------------------------------------------------------
+#define SMX_SEEDS_CAND 20
+struct ClosePick {  // running minimum of (score, d2, index)
+  double score, d2;
+  int idx;
+  __device__ __forceinline__ void none() {
+    score = d2 = SMX_INF;
+    idx = -1;
+  }
+  __device__ __forceinline__ void offer(double sc, double q2, int i) {
+    if (sc < score || (sc == score && (q2 < d2 || (q2 == d2 && i < idx)))) {
+      score = sc;
+      d2 = q2;
+      idx = i;
+    }
+  }
+};
+
+// Returns false when the vehicle has to take the ten-nearest form (no usable carry, a list overflow, more than ten
+// members in C, a reach beyond the seeded span, the closest lanepoint on a junction road).  `d1sq`: d2 of the nearest lanepoint (for the next tick's carry).
+__device__ inline bool seeds_one_lane(const MapDev& m, double px, double py, double heading, double within_radius,
+                                      const SeedsCarry& c, int* cand, int stride, PathSeeds& s, double& d1sq) {
+  if (!(c.valid && c.d1 >= 0.0 && c.d1 < 1.0e290 && c.qx == c.qx && c.qy == c.qy)) return false;
+  const double b = (sqrt(c.d1) + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;  // d(nearest) now is at most this
+  const double t_pre = (b * b + SMX_PI) * (1.0 + 1e-12) + 1e-9;                       // ... and T at most this
+  double reach = sqrt(t_pre) * (1.0 + 1e-12) + 1e-9;
+  // the road the paths started on last tick: its lanes' nearest lanepoints ride along (a guess, checked below)
+  int k0 = -9, k1 = -9, k2 = -9, k3 = -9, nk = 0;
+  if (c.prev_road >= 0 && c.prev_lanes >= 1) {
+    nk = min(c.prev_lanes, SMX_SEED_LANES);
+    const int la = m.road_lane_off[c.prev_road];
+    k0 = m.road_lanes[la];
+    k1 = nk > 1 ? m.road_lanes[la + 1] : -9;
+    k2 = nk > 2 ? m.road_lanes[la + 2] : -9;
+    k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < SMX_SEED_LANES; ++q) {
+      const int st = c.prev_start[q];
+      if (q < nk) {
+        if (st >= 0) {
+          const smx_lp_rec* r = m.lp_rec + st;
+          reach = fmax(reach, euclid(px, py, r->x, r->y) * (1.0 + 1e-12) + 1e-9);
+        } else {
+          all = false;
+        }
+      }
+    }
+    if (!all) nk = 0;
+  }
+  int cx0 = (int)floor((px - reach - m.lpg_x0) / m.lpg_cell), cx1 = (int)floor((px + reach - m.lpg_x0) / m.lpg_cell);
+  int cy0 = (int)floor((py - reach - m.lpg_y0) / m.lpg_cell), cy1 = (int)floor((py + reach - m.lpg_y0) / m.lpg_cell);
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, m.lpg_nx - 1);
+  cy1 = min(cy1, m.lpg_ny - 1);
+  if (cx0 > cx1 || cy0 > cy1 || cy1 - cy0 >= SMX_SEEDED_SPAN || cx1 - cx0 >= SMX_SEEDED_SPAN) return false;
+  // ---- pass 1
+  int ra[SMX_SEEDED_SPAN], rn[SMX_SEEDED_SPAN];
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < SMX_SEEDED_SPAN; ++i) {
+    const int y = cy0 + i;
+    const bool in = y <= cy1;
+    const int row = (in ? y : cy0) * m.lpg_nx;
+    const int va = m.lpg_off[row + cx0], vb = m.lpg_off[row + cx1 + 1];
+    ra[i] = va;
+    total += in ? vb - va : 0;
+    rn[i] = total;
+  }
+  auto member = [&](int n) {
+    int k = ra[0] + n;
+#pragma unroll
+    for (int i = 1; i < SMX_SEEDED_SPAN; ++i)
+      if (n >= rn[i - 1]) k = ra[i] + (n - rn[i - 1]);
+    return k;
+  };
+  double g2 = SMX_INF;  // nearest lanepoint: smallest (d2, index)
+  int gi = 0x7fffffff;
+  double bd[4] = {SMX_INF, SMX_INF, SMX_INF, SMX_INF};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int n = 0;
+  bool overflow = false;
+  auto take = [&](const smx_pt_rec& p, int k) {
+    const double dx = p.x - px, dy = p.y - py;
+    const double d2 = dx * dx + dy * dy;
+    if (d2 < g2 || (d2 == g2 && p.idx < gi)) {
+      g2 = d2;
+      gi = p.idx;
+    }
+    if (d2 <= t_pre) {
+      if (n < SMX_SEEDS_CAND)
+        cand[n * stride] = k;
+      else
+        overflow = true;
+      ++n;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+      if (q < nk && p.lane == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+        bd[q] = d2;
+        bi[q] = p.idx;
+      }
+    }
+  };
+  for (int n0 = 0; n0 < total; n0 += 4) {
+    smx_pt_rec rec[4];
+    int kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      kk[u] = member(n0 + u < total ? n0 + u : 0);
+      rec[u] = m.lpg_pts[kk[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (n0 + u < total) take(rec[u], kk[u]);
+  }
+  if (overflow || gi == 0x7fffffff) return false;
+  d1sq = g2;
+  // ---- pass 2: the members of C, scored
+  const double t_c = g2 + SMX_PI;
+  const double r2 = within_radius * within_radius;
+  ClosePick any, near;  // closest_lanepoints(pose) without a radius, and within `within_radius`
+  any.none();
+  near.none();
+  int n_c = 0;
+  for (int i = 0; i < n; ++i) {
+    const smx_pt_rec p = m.lpg_pts[cand[i * stride]];
+    const double dx = p.x - px, dy = p.y - py;
+    const double d2 = dx * dx + dy * dy;
+    if (!(d2 <= t_c)) continue;
+    ++n_c;
+    const double rel = fabs(heading_relative_to(heading, m.lp_rec[p.idx].heading));
+    const double score = d2 + rel;
+    any.offer(score, d2, p.idx);
+    if (p.idx == gi || d2 <= r2) near.offer(score, d2, p.idx);
+  }
+  if (n_c > 10) return false;
+  // ---- team_compute_path_seeds, an agent with a (possibly empty) route object and no fixed route
+  s.f.none();
+  s.road = -1;
+  s.n_lanes = 0;
+#pragma unroll
+  for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
+  {
+    const int lp = any.idx;
+    const int road = m.lane_road[m.lp_rec[lp].lane];
+    // _resolve_in_junction (sumo_road_network.py:842-860): the closest lanepoint lies on a junction road — the
+    // searches by road that follow are the team form's (few vehicles are inside a junction at any time)
+    if (m.road_is_junction[road]) return false;
+  }
+  s.road = near.idx >= 0 ? m.lane_road[m.lp_rec[near.idx].lane] : -1;
+  if (s.road >= 0) {
+    const int la = m.road_lane_off[s.road], lb = m.road_lane_off[s.road + 1];
+    s.n_lanes = lb - la;
+    const int nq = min(s.n_lanes, SMX_SEED_LANES);
+    bool guessed = s.road == c.prev_road && nq == nk && nk > 0;
+#pragma unroll
+    for (int q = 0; q < SMX_SEED_LANES; ++q) guessed = guessed && (q >= nk || bi[q] != 0x7fffffff);
+    if (guessed) {
+#pragma unroll
+      for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = q < nq ? bi[q] : -1;
+    } else {
+      const int q0 = m.road_lanes[la], q1 = nq > 1 ? m.road_lanes[la + 1] : -9, q2 = nq > 2 ? m.road_lanes[la + 2] : -9,
+                q3 = nq > 3 ? m.road_lanes[la + 3] : -9;
+      team_closest_filtered4<1>(m, px, py, q0, q1, q2, q3, nq, false, s.start, nullptr);
+    }
+  }
+  return true;
+}
 
 // ---------------------------------------------------------------------------------
 // One-lane (serial) forms for the rare questions of the event code: offset_along_lane

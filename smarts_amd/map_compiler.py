@@ -431,7 +431,7 @@ SHAPE_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("cum", "<f8"), ("len", "<f8")
 SUCC_REC = np.dtype([("idx", "<i4"), ("lane", "<i4"), ("knot", "<i4"), ("hops", "<i4")], align=False)
 PT_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("idx", "<i4"), ("lane", "<i4")], align=False)
 SEG_REC = np.dtype([("x1", "<f8"), ("y1", "<f8"), ("x2", "<f8"), ("y2", "<f8"), ("thr", "<f8"), ("lane", "<i4"),
-                    ("pad", "<i4")], align=False)
+                    ("v0", "<i4")], align=False)
 assert LP_REC.itemsize == 64 and SUCC_REC.itemsize == 16 and PT_REC.itemsize == 24 and SEG_REC.itemsize == 48
 
 
@@ -499,6 +499,7 @@ def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
     # road_with_point threshold, the reference's expression (sumo_road_network.py:707)
     seg["thr"] = np.array([0.5 * float(w) + 1e-1 for w in cm.lane_width[lane]])
     seg["lane"] = lane
+    seg["v0"] = v0
     # centre-line vertices with their running arclength: the sums follow the reference's loops
     # (utils/math.py:319-331, 370-390: `seen += length` vertex by vertex), so offsets compare equal
     shp = np.zeros(len(cm.shape_x), dtype=SHAPE_REC)

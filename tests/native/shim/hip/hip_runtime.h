@@ -14,3 +14,10 @@
 using std::max;
 using std::min;
 // (glibc declares sincos itself)
+
+// One-lane "teams" (smx_scan.h with TEAM = 1): a shuffle returns the lane's own value.
+struct ShimDim3 { unsigned x, y, z; };
+static const ShimDim3 threadIdx = {0, 0, 0};
+template <class T> inline T __shfl_xor(T v, int, int = 64) { return v; }
+template <class T> inline T __shfl(T v, int, int = 64) { return v; }
+template <class T> inline T __shfl_up(T v, unsigned, int = 64) { return v; }

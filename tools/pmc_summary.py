@@ -8,6 +8,8 @@ def kernel_name(raw):
     name = raw.split("(")[0].strip()
     if name.startswith("void "):
         name = name[5:]
+    if name.startswith("k_scan_half<"):  # the two halves are different kernels
+        return name.split(",")[0] + ">"
     return name.split("<")[0]
 
 
