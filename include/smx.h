@@ -192,6 +192,7 @@ typedef struct smx_pt_rec { double x, y; int32_t idx, lane; } smx_pt_rec;   /* l
 typedef struct smx_seg_rec {  /* centre-line segment grid member */
   double x1, y1, x2, y2;
   double thr;                 /* 0.5 * lane width + 0.1 (road_with_point, sumo_road_network.py:707) */
+  double len, cum;            /* shape_rec[v0].len / .cum: the segment's length and its arclength along the lane */
   int32_t lane;
   int32_t v0;                 /* index of the segment's first vertex in shape_rec (its second one is v0 + 1) */
 } smx_seg_rec;

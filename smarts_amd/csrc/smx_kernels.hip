@@ -46,6 +46,9 @@
 // ticks 50-550 of a run (fewer alive) 0.223 / 0.250 — the longer run decides, 16 384 stays small.
 #define SMX_LARGE_BATCH_VEHICLES 16384
 #define SMX_WPT_PRELOAD 8           // knots of a path held in registers while it is interpolated
+#ifndef SMX_WP_STAGED
+#define SMX_WP_STAGED 0             // developer variant (-DSMX_WP_STAGED=1): k_waypoints_tables instead of k_waypoints_emit
+#endif
 #define SMX_SLOW_BLOCKS 512          // workgroups of k_scan_listed (the slow list's length is only known on the device)
 #ifndef SMX_SCAN_UNSEEDED
 #define SMX_SCAN_UNSEEDED 0         // developer variant (-DSMX_SCAN_UNSEEDED=1): the scan never starts from last tick's answers
@@ -85,6 +88,8 @@ struct KernelArgs {
   // large batches: vehicles the one-lane scan kernels could not serve (k_scan_fast -> k_scan_half over this list)
   int32_t* slow_list;
   int32_t* slow_count;
+  // [E*N], 1: the vehicle's path seeds, walks and rows are the slow chain's this tick (k_scan_fast<1> decides; null: none)
+  uint8_t* seed_pending;
 };
 enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 was met (and treated as "no action")
 
@@ -93,7 +98,10 @@ enum { SMX_DEVICE_BAD_LANE_ACTION = 1 };  // a Lane action code outside -1..3 wa
 // The vehicle that team (or lane) i of a per-vehicle launch works on; `total` = none (i is past the last one).
 __device__ __forceinline__ size_t launch_vehicle(const KernelArgs& a, size_t i, size_t total) {
   if (a.alive_list == nullptr) return i < total ? i : total;
-  return i < (size_t)*a.alive_count ? (size_t)a.alive_list[i] : total;
+  // (the entry is loaded beside the count, not behind it: one round trip; entries past the count are old vehicle
+  // numbers or zeros, in range either way)
+  const int32_t entry = a.alive_list[i < total ? i : total - 1];
+  return i < (size_t)*a.alive_count ? (size_t)entry : total;
 }
 
 // Developer timing switches ("switch a piece off and see what the tick costs without it"): they exist
@@ -582,14 +590,11 @@ __device__ __forceinline__ bool decode_lane_action(const KernelArgs& a, size_t g
 }
 
 template <int SPACE>
-__global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a, const CtrlHandoff ho) {
-  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
-  int* knots = knot_scratch + threadIdx.x;
+__device__ __forceinline__ void control_paths_for(const KernelArgs& a, const CtrlHandoff& ho, const size_t gid, int* knots) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int p0 = threadIdx.x % SMX_WP_LANES;
-  const size_t gid = launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, total);
   if (gid >= total) return;  // whole teams leave together
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE) || (flags & SMX_F_SOCIAL)) return;
@@ -827,14 +832,30 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a,
   ho.n[gid] = n < SMX_CTRL_WPS ? n : SMX_CTRL_WPS;
 }
 
+// One team of four lanes per vehicle.  With a slow list in the arguments (large batches: the vehicles k_control_fast
+// could not serve) a fixed grid strides that list, whose length is only known on the device.
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a, const CtrlHandoff ho) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  int* knots = knot_scratch + threadIdx.x;
+  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  constexpr int VPB = SMX_BLOCK / SMX_WP_LANES;
+  if (a.slow_list != nullptr) {
+    const int count = *a.slow_count;
+    for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
+      control_paths_for<SPACE>(a, ho, (size_t)a.slow_list[i], knots);
+    return;
+  }
+  control_paths_for<SPACE>(a, ho, launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, total), knots);
+}
+
 // Control law + vehicle dynamics, one lane per vehicle (see k_control_paths).  Every action space; the
 // lane-following ones read the wanted path from the hand-off.
 template <int SPACE>
-__global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, const CtrlHandoff ho) {
+__device__ __forceinline__ void control_law_for(const KernelArgs& a, const CtrlHandoff& ho, const size_t gid) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
   if (gid >= total) return;
   int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
@@ -937,6 +958,301 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, c
   SF(SMX_S_MCL_X) = cs.mcl_x;
   SF(SMX_S_MCL_Y) = cs.mcl_y;
   a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
+}
+
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, const CtrlHandoff ho) {
+  if (a.slow_list != nullptr) {  // the vehicles k_control_fast left to k_control_paths (see there)
+    const int count = *a.slow_count;
+    for (int i = (int)blockIdx.x * SMX_BLOCK + (int)threadIdx.x; i < count; i += (int)gridDim.x * SMX_BLOCK)
+      control_law_for<SPACE>(a, ho, (size_t)a.slow_list[i]);
+    return;
+  }
+  control_law_for<SPACE>(a, ho, (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x);
+}
+
+// =================================================================================
+// k_control_fast (large batches, lane-following action spaces): controller + dynamics with ONE lane per vehicle and
+// no hand-off.  The controller's candidate paths start on the seeds the waypoints sensor walked last tick
+// (k_control_paths explains the reuse): find_current_lane needs the start lanepoints only, and the wanted path's
+// 17 waypoints are interpolated from its knot list straight into this lane's LDS column, read back with fixed
+// indices by the control law.  k_control_paths wrote them to device memory for k_control_law to read back (115 MB
+// each way at 131 k vehicles) with three of its four lanes idle during the interpolation.  A vehicle whose lists
+// cannot be reused — a new vehicle, a branching inside the lookahead, a road of more than four lanes — goes to the
+// slow list and through k_control_paths / k_control_law as before.
+// =================================================================================
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_fast(const KernelArgs a) {
+  __shared__ double path_lds[3 * SMX_CTRL_WPS * SMX_BLOCK];
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const size_t gid = launch_vehicle(a, (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x, total);
+  bool slow = false;
+  // ---- every word whose address only needs the vehicle, loaded together and whatever the flags say (two wavefronts
+  // per SIMD hide nothing: flags -> action -> seeds -> list keys -> ... one behind the other was a microsecond each)
+  const bool in_range = gid < total;
+  const size_t g = in_range ? gid : 0;
+  int flags = a.st.flags[g];
+  int action = SMX_ACTION_NONE;
+  float act0 = 0.f, act1 = 0.f;
+  if (SPACE == SMX_ACTION_SPACE_LANE) {
+    action = a.actions[g];
+  } else {
+    act0 = a.actions_f32[g * 3 + 0];
+    act1 = a.actions_f32[g * 3 + 1];
+  }
+  VehState s;
+  CtrlState cs;
+  {
+    const double* f = a.st.f64 + g;
+    s.x = f[(size_t)SMX_S_X * total];
+    s.y = f[(size_t)SMX_S_Y * total];
+    s.heading = f[(size_t)SMX_S_HEADING * total];
+    s.u = f[(size_t)SMX_S_U * total];
+    s.v = f[(size_t)SMX_S_V * total];
+    s.r = f[(size_t)SMX_S_R * total];
+    s.delta = f[(size_t)SMX_S_DELTA * total];
+    cs.lat_int = f[(size_t)SMX_S_LAT_INT * total];
+    cs.spd_int = f[(size_t)SMX_S_SPD_INT * total];
+    cs.steer = f[(size_t)SMX_S_STEER * total];
+    cs.throttle = f[(size_t)SMX_S_THROTTLE * total];
+    cs.spd_err = f[(size_t)SMX_S_SPD_ERR * total];
+    cs.mcl_x = f[(size_t)SMX_S_MCL_X * total];
+    cs.mcl_y = f[(size_t)SMX_S_MCL_Y * total];
+  }
+  const PathSeeds seed = load_seeds(a, g, total);
+  const bool lists = a.knots.key != nullptr;
+  const size_t paths = total * SMX_WP_LANES;
+  int kn_n[SMX_WP_LANES], kn_key0[SMX_WP_LANES], kn_key1[SMX_WP_LANES], kn_key2[SMX_WP_LANES], kn_cnt[SMX_WP_LANES],
+      kn_nk16[SMX_WP_LANES], kn_end16[SMX_WP_LANES];
+#pragma unroll
+  for (int q = 0; q < SMX_WP_LANES; ++q) {
+    const size_t pth = g * SMX_WP_LANES + q;
+    kn_n[q] = lists ? (int)a.knots.n[pth] : 0;
+    kn_key0[q] = lists ? a.knots.key[pth] : -1;
+    kn_key1[q] = lists ? a.knots.key[paths + pth] : -1;
+    kn_key2[q] = lists ? a.knots.key[2 * paths + pth] : -1;
+    kn_cnt[q] = lists ? (int)a.knots.cnt[pth] : 0;
+    kn_nk16[q] = lists ? (int)a.knots.nk16[pth] : 0;
+    kn_end16[q] = lists ? a.knots.end16[pth] : -1;
+  }
+  if (in_range && (flags & SMX_F_ALIVE)) {
+    if (flags & SMX_F_SOCIAL) {  // scripted lane follower: no controller, no dynamics
+      int lane = (int)cs.mcl_x, crossed = (int)cs.spd_int;
+      double offset = cs.mcl_y, speed, x, y, heading;
+      SF(SMX_S_PREV_X) = s.x;
+      SF(SMX_S_PREV_Y) = s.y;
+      const double cmd = c.social_model == SMX_SOCIAL_IDM ? cs.throttle : -1.0;
+      social_step(m, (int)(gid % c.num_vehicles), c.social_speed_factor, c.dt, lane, offset, crossed, speed, cmd);
+      social_pose(m, lane, offset, x, y, heading);
+      SF(SMX_S_X) = x;
+      SF(SMX_S_Y) = y;
+      SF(SMX_S_HEADING) = heading;
+      SF(SMX_S_U) = speed;
+      SF(SMX_S_MCL_X) = (double)lane;
+      SF(SMX_S_MCL_Y) = offset;
+      SF(SMX_S_SPD_INT) = (double)crossed;
+    } else {
+      // Controllers.perform_action's decoding (decode_lane_action, on the words loaded above)
+      double target_speed = 0.0, hg = 0.0, lg = 0.0;
+      int lane_change = 0;
+      bool has_action = false;
+      if (SPACE == SMX_ACTION_SPACE_LANE) {
+        if (action < SMX_ACTION_NONE || action > SMX_ACTION_CHANGE_LANE_RIGHT) {
+          atomicOr(a.status, SMX_DEVICE_BAD_LANE_ACTION);  // reported at the next smx_sync; the code moves nothing
+        } else if (action >= 0) {
+          has_action = true;
+          target_speed = action == SMX_ACTION_KEEP_LANE ? 15.0 : (action == SMX_ACTION_SLOW_DOWN ? 0.0 : 12.5);
+          lane_change = action == SMX_ACTION_CHANGE_LANE_LEFT ? 1 : (action == SMX_ACTION_CHANGE_LANE_RIGHT ? -1 : 0);
+          hg = target_speed > 0.0 ? a.heading_gain_pos : 0.01;
+          lg = target_speed > 0.0 ? a.lateral_gain_pos : 0.36;
+        }
+      } else if (!(act0 != act0)) {  // NaN = no action
+        has_action = true;
+        target_speed = (double)act0;
+        lane_change = (int)act1;
+        lateral_gains_for_speed(target_speed, hg, lg);
+      }
+      CtrlPath path;
+      path.n = 0;
+      if (has_action && !SMX_SKIP(a, 1 << 26)) {
+        // ---- the wanted path from the sensor's knot lists (k_control_paths' reuse, one lane doing the team's part)
+        const double px = s.x, py = s.y;
+        if (!lists || c.wp_lookahead < SMX_CTRL_WPS - 1 || (seed.road >= 0 && seed.n_lanes > SMX_WP_LANES)) {
+          slow = true;
+        } else if (seed.road >= 0) {
+          const int f0 = seed.f.n > 0 ? seed.f.road[0] : -1, f1 = seed.f.n > 1 ? seed.f.road[1] : -1;
+          int started = 0, qw = 0;
+          double my_d = SMX_INF;
+          int my_idx = 0;
+          // the start lanepoints' records, together
+          double rx[SMX_WP_LANES], ry[SMX_WP_LANES], rdx[SMX_WP_LANES], rdy[SMX_WP_LANES], rh[SMX_WP_LANES];
+          int st[SMX_WP_LANES];
+#pragma unroll
+          for (int q = 0; q < SMX_WP_LANES; ++q) {
+            st[q] = q < seed.n_lanes ? seed_start(m, seed, q, px, py) : -1;
+            const smx_lp_rec* r = m.lp_rec + (st[q] >= 0 ? st[q] : 0);
+            rx[q] = r->x;
+            ry[q] = r->y;
+            rdx[q] = r->dirx;
+            rdy[q] = r->diry;
+            rh[q] = r->heading;
+          }
+          // every seed lane's list must be this tick's; the nearest first waypoint (find_current_lane,
+          // lane_following_controller.py:367-374: np.argmin, the lowest path number wins ties)
+#pragma unroll
+          for (int q = 0; q < SMX_WP_LANES; ++q) {
+            if (st[q] >= 0) {
+              const int n32 = kn_n[q];
+              if (!(kn_key0[q] == st[q] && kn_key1[q] == f0 && kn_key2[q] == f1 && kn_cnt[q] == 1 && n32 > 0)) slow = true;
+              const double proj = (px - rx[q]) * rdx[q] + (py - ry[q]) * rdy[q];
+              const double fx = n32 == 1 ? rx[q] : rx[q] + proj * rdx[q], fy = n32 == 1 ? ry[q] : ry[q] + proj * rdy[q];
+              const double ex = fx - px, ey = fy - py;
+              const double d = sqrt(ex * ex + ey * ey);
+              if (d < my_d) {
+                my_d = d;
+                my_idx = __popc(started);
+              }
+              started |= 1 << q;
+            }
+          }
+          const int n_paths = __popc(started);
+          if (!slow && n_paths > 0) {
+            int want = my_idx + lane_change;
+            want = want < 0 ? 0 : (want > n_paths - 1 ? n_paths - 1 : want);
+            // the want-th started seed lane
+#pragma unroll
+            for (int q = 0; q < SMX_WP_LANES; ++q)
+              if ((started >> q) & 1)
+                if (__popc(started & ((1 << q) - 1)) == want) qw = q;
+            int n32w = 0, nk16 = 0, last = -1;
+            smx_lp_rec r0 = smx_lp_rec{};
+#pragma unroll
+            for (int q = 0; q < SMX_WP_LANES; ++q)
+              if (q == qw) {
+                n32w = kn_n[q];
+                nk16 = kn_nk16[q];
+                last = kn_end16[q];  // the last knot when it is not one of the list's
+                r0.x = rx[q];
+                r0.y = ry[q];
+                r0.dirx = rdx[q];
+                r0.diry = rdy[q];
+                r0.heading = rh[q];
+              }
+            r0.lane = 0;  // (lane, width and speed limit of the waypoints are not the controller's business)
+            const size_t pth = gid * SMX_WP_LANES + qw;
+            const int n16 = n32w < SMX_CTRL_WPS ? n32w : SMX_CTRL_WPS;
+            auto fetch = [&](int k) { return (k == nk16 - 1 && last >= 0) ? last : a.knots.idx[(size_t)(k + 1) * paths + pth]; };
+            constexpr int KP = SMX_WPT_PRELOAD;
+            double kx[KP], ky[KP], kh[KP], kw[KP], ks_[KP];
+            int kl[KP];
+            {
+              int kid[KP];
+#pragma unroll
+              for (int k = 0; k < KP; ++k) kid[k] = a.knots.idx[(size_t)(k + 1) * paths + pth];  // (in range whatever nk16 is)
+#pragma unroll
+              for (int k = 0; k < KP; ++k) {
+                const bool have = k < nk16;
+                const int id = (k == nk16 - 1 && last >= 0) ? last : kid[k];
+                const smx_lp_rec* r = m.lp_rec + (have ? id : 0);
+                kx[k] = have ? r->x : 0.0;
+                ky[k] = have ? r->y : 0.0;
+                kh[k] = have ? r->heading : 0.0;
+                kl[k] = 0;
+                kw[k] = 0.0;
+                ks_[k] = 0.0;
+              }
+            }
+            double D = 0.0;
+            {
+              const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+              double lastx = r0.x + proj * r0.dirx, lasty = r0.y + proj * r0.diry;
+#pragma unroll
+              for (int k = 0; k < KP; ++k) {
+                if (k < nk16) {
+                  const double ex = kx[k] - lastx, ey = ky[k] - lasty;
+                  D += sqrt(ex * ex + ey * ey);
+                  lastx = kx[k];
+                  lasty = ky[k];
+                }
+              }
+              for (int k = KP; k < nk16; ++k) {
+                const smx_lp_rec* r = m.lp_rec + fetch(k);
+                const double qx = r->x, qy = r->y;
+                const double ex = qx - lastx, ey = qy - lasty;
+                D += sqrt(ex * ex + ey * ey);
+                lastx = qx;
+                lasty = qy;
+              }
+            }
+            double* col = path_lds + threadIdx.x;
+            interpolate_knots_preloaded<KP>(m, r0, 0.0, 0.0, nk16, n16, D, px, py, SMX_CTRL_WPS, kx, ky, kh, kl, kw, ks_, fetch,
+                                            [&](int i, const WaypointOut& w) {
+                                              double* q = col + (size_t)(i * 3) * SMX_BLOCK;
+                                              q[0] = w.x;
+                                              q[SMX_BLOCK] = w.y;
+                                              q[2 * SMX_BLOCK] = w.heading;
+                                            });
+            path.n = n16;
+#pragma unroll
+            for (int k = 0; k < SMX_CTRL_WPS; ++k) {
+              const double* q = col + (size_t)(k * 3) * SMX_BLOCK;
+              const bool held = k < n16;
+              path.x[k] = held ? q[0] : 0.0;
+              path.y[k] = held ? q[SMX_BLOCK] : 0.0;
+              path.h[k] = held ? q[2 * SMX_BLOCK] : 0.0;
+            }
+          }
+        }
+      }
+      if (!slow) {
+        cs.mcl_set = (flags & SMX_F_MCL_SET) != 0;
+        ControlOut co;
+        // no action this tick: wheel torques do not persist, the steer motor target does
+        co.throttle = 0.0;
+        co.brake = 0.0;
+        co.steering = cs.steer;
+        if (has_action) {
+          if (path.n > 0 && !SMX_SKIP(a, 1 << 28)) {
+            co = lane_following_from_path(s, cs, c.dt, target_speed, lane_change, hg, lg, path);
+          } else {
+            // reference asserts "no waypoints found"; keep the last command
+            co.throttle = cs.throttle;
+            co.brake = 0.0;
+            co.steering = cs.steer;
+          }
+        }
+        SF(SMX_S_PREV_X) = s.x;  // the position recorded by the previous observation
+        SF(SMX_S_PREV_Y) = s.y;
+        if (!SMX_SKIP(a, 1 << 27)) vehicle_step(s, co, c.dt);
+        SF(SMX_S_X) = s.x;
+        SF(SMX_S_Y) = s.y;
+        SF(SMX_S_HEADING) = s.heading;
+        SF(SMX_S_U) = s.u;
+        SF(SMX_S_V) = s.v;
+        SF(SMX_S_R) = s.r;
+        SF(SMX_S_DELTA) = s.delta;
+        SF(SMX_S_LAT_INT) = cs.lat_int;
+        SF(SMX_S_SPD_INT) = cs.spd_int;
+        SF(SMX_S_STEER) = cs.steer;
+        SF(SMX_S_THROTTLE) = cs.throttle;
+        SF(SMX_S_SPD_ERR) = cs.spd_err;
+        SF(SMX_S_MCL_X) = cs.mcl_x;
+        SF(SMX_S_MCL_Y) = cs.mcl_y;
+        a.st.flags[gid] = cs.mcl_set ? (flags | SMX_F_MCL_SET) : (flags & ~SMX_F_MCL_SET);
+      }
+    }
+  }
+  // the wavefront's slow vehicles, appended with one atomic
+  const unsigned long long mask = __ballot(slow);
+  if (mask != 0ull) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(a.slow_count, __popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (slow) a.slow_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
+  }
 }
 
 // =================================================================================
@@ -1180,38 +1496,68 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const size_t gid = launch_vehicle(a, (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x, total);
   bool slow = false;
-  const int flags = gid < total ? a.st.flags[gid] : 0;
-  if (gid < total && (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST))) {
-    const VehState s = load_vehicle(a, gid, total);
-    int32_t* fi = a.st.facts_i32;
+  // every word whose address only needs the vehicle is loaded here, together and whatever the flags say (one round
+  // trip instead of flags -> pose -> carry one behind the other: two wavefronts per SIMD hide nothing)
+  const bool in_range = gid < total;
+  const size_t g = in_range ? gid : 0;
+  const int flags = a.st.flags[g];
+  const double sx_ = a.st.f64[(size_t)SMX_S_X * total + g], sy_ = a.st.f64[(size_t)SMX_S_Y * total + g],
+               sh_ = a.st.f64[(size_t)SMX_S_HEADING * total + g];
+  int32_t* fi = a.st.facts_i32;
+  FactsCarry fc;
+  SeedsCarry scy;
+  fc.valid = false;
+  scy.valid = false;
+  int prev_lane = -1;
+  if (ROLE == 0) {
+    fc.qx = a.facts_carry[g];
+    fc.qy = a.facts_carry[total + g];
+    fc.prev_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + g];
+    prev_lane = fi[(size_t)SMX_FI_LANE * total + g];
+  } else {
+    const int32_t* sc_ = a.st.seed_cache;
+    scy.qx = a.seeds_carry[g];
+    scy.qy = a.seeds_carry[total + g];
+    scy.d10 = a.seeds_carry[2 * total + g];
+    scy.d1 = a.seeds_carry[3 * total + g];
+    scy.prev_road = sc_[0 * total + g];
+    scy.prev_lanes = sc_[4 * total + g];
+#pragma unroll
+    for (int q = 0; q < SMX_SEED_LANES; ++q) scy.prev_start[q] = sc_[(size_t)(5 + q) * total + g];
+  }
+  if (in_range && (flags & SMX_F_ALIVE) && (!a.first_only || (flags & SMX_F_FIRST))) {
     int* cand = cand_lds + threadIdx.x;
+    const bool seeded = !(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED;
     if (ROLE == 0) {
       const double cxs[4] = {-0.5, 0.5, 0.5, -0.5};
       const double cys[4] = {0.5, 0.5, -0.5, -0.5};
       double cx[4], cy[4];
-      const double ch = cos(s.heading), sh = sin(s.heading);
+      const double ch = cos(sh_), sh = sin(sh_);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        double qx = s.x + cxs[q] * SMX_CHASSIS_WIDTH;
-        double qy = s.y + cys[q] * SMX_CHASSIS_LENGTH;
-        cx[q] = s.x + ch * (qx - s.x) + sh * (qy - s.y);
-        cy[q] = s.y + -sh * (qx - s.x) + ch * (qy - s.y);
+        double qx = sx_ + cxs[q] * SMX_CHASSIS_WIDTH;
+        double qy = sy_ + cys[q] * SMX_CHASSIS_LENGTH;
+        cx[q] = sx_ + ch * (qx - sx_) + sh * (qy - sy_);
+        cy[q] = sy_ + -sh * (qx - sx_) + ch * (qy - sy_);
       }
       const bool social = (flags & SMX_F_SOCIAL) != 0;
-      FactsCarry fc;
-      fc.valid = false;
-      if (!(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
-        fc.qx = a.facts_carry[gid];
-        fc.qy = a.facts_carry[total + gid];
-        fc.prev_dist = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
-        fc.valid = fi[(size_t)SMX_FI_LANE * total + gid] >= 0;
-      }
+      fc.valid = seeded && prev_lane >= 0;
       RoadFacts h;
       double lane_heading = 0.0;
-      if (facts_one_lane(m, s.x, s.y, SMX_POSE_SCAN_RADIUS, social ? 0 : 4, cx, cy, fc, a.dagm_reach + 0.1, cand, SMX_BLOCK,
-                         !social, h, lane_heading)) {
-        a.facts_carry[gid] = s.x;
-        a.facts_carry[total + gid] = s.y;
+      bool served;
+      if (SMX_SKIP(a, 1 << 23)) {  // (developer ablation: the prologue and the stores only)
+        h.lane = prev_lane;
+        h.dist = fc.prev_dist + cx[0] * 1e-30;
+        h.on_road = true;
+        h.corner_mask = 15;
+        served = true;
+      } else {
+        served = facts_one_lane(m, sx_, sy_, SMX_POSE_SCAN_RADIUS, social ? 0 : 4, cx, cy, fc, a.dagm_reach + 0.1, cand, SMX_BLOCK,
+                                !social, h, lane_heading);
+      }
+      if (served) {
+        a.facts_carry[gid] = sx_;
+        a.facts_carry[total + gid] = sy_;
         fi[(size_t)SMX_FI_LANE * total + gid] = h.lane;
         fi[(size_t)SMX_FI_FLAGS * total + gid] =
             (h.on_road ? SMX_FACT_ON_ROAD : 0) | ((h.corner_mask & 15) << SMX_FACT_CORNER_SHIFT);
@@ -1221,33 +1567,23 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
         slow = true;
       }
     } else if (!(flags & SMX_F_SOCIAL)) {
-      SeedsCarry scy;
-      scy.valid = false;
-      if (!(flags & SMX_F_FIRST) && !SMX_SCAN_UNSEEDED) {
-        const int32_t* sc_ = a.st.seed_cache;
-        scy.qx = a.seeds_carry[gid];
-        scy.qy = a.seeds_carry[total + gid];
-        scy.d10 = a.seeds_carry[2 * total + gid];
-        scy.d1 = a.seeds_carry[3 * total + gid];
-        scy.prev_road = sc_[0 * total + gid];
-        scy.prev_lanes = sc_[4 * total + gid];
-#pragma unroll
-        for (int q = 0; q < SMX_SEED_LANES; ++q) scy.prev_start[q] = sc_[(size_t)(5 + q) * total + gid];
-        scy.valid = true;
-      }
+      scy.valid = seeded;
       PathSeeds one;
       double d1sq = -1.0;
-      if (seeds_one_lane(m, s.x, s.y, s.heading, 5.0, scy, cand, SMX_BLOCK, one, d1sq)) {
-        a.seeds_carry[gid] = s.x;
-        a.seeds_carry[total + gid] = s.y;
+      if (seeds_one_lane(m, sx_, sy_, sh_, 5.0, scy, cand, SMX_BLOCK, one, d1sq)) {
+        a.seeds_carry[gid] = sx_;
+        a.seeds_carry[total + gid] = sy_;
         a.seeds_carry[2 * total + gid] = -1.0;  // (the tenth nearest was not looked for)
         a.seeds_carry[3 * total + gid] = d1sq;
         store_seeds(a, gid, total, one);
         fi[(size_t)SMX_FI_TRIP_START * total + gid] = -1;  // (only a new vehicle or a batch without the waypoints
         fi[(size_t)SMX_FI_OBS_START * total + gid] = -1;   //  sensor asks these: neither comes here)
       } else {
+        // its seeds, walks and rows are the slow chain's (k_scan_listed -> k_waypoints_listed, beside the tick's main
+        // chain): k_wp_walk and k_waypoints_emit pass over the vehicle
         slow = true;
       }
+      if (a.seed_pending != nullptr) a.seed_pending[gid] = slow ? 1 : 0;
     }
   }
   // the wavefront's slow vehicles, appended with one atomic
@@ -1737,7 +2073,7 @@ __global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs
   const unsigned long long mask = __ballot(alive);
   if (gid == 0) {
     *count_next = 0;
-    slow_next[0] = slow_next[1] = 0;  // the slow lists of the next tick's one-lane scan (facts, seeds)
+    slow_next[0] = slow_next[1] = slow_next[2] = slow_next[3] = 0;  // the slow lists of the next tick's fast kernels
   }
   if (lane == 0) wave_base[wave] = __popcll(mask);
   __syncthreads();
@@ -1770,7 +2106,9 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
   const int flags = a.st.flags[gid];
   int n = 0, nk = 0, cnt = 0;
   double D = 0.0;
-  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST))) {
+  // (a vehicle whose seeds the slow chain is still looking for has no list this tick: k_scan_fast)
+  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST)) &&
+      !(a.seed_pending != nullptr && a.seed_pending[gid])) {
     const PathSeeds seed = load_seeds(a, gid, total);
     if (seed.road >= 0 && seed.n_lanes <= SMX_WP_LANES && p0 < seed.n_lanes) {
       const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
@@ -2139,6 +2477,402 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
   if (live && p0 == 0) trip_meter_update<SMX_BLOCK>(a, m, gid, total, flags, px, py, knots, have_first_wp, fwx, fwy, fwh);
   SMX_TSTAMP(tw6);
   SMX_TACC(3, tw0, tw6);
+}
+
+// =================================================================================
+// waypoints role, emit-parallel form (large batches, round 3): the same rows as waypoints_tables_role, one lane per
+// WAYPOINT instead of one lane per path.
+//   The staged form interpolates one path per lane: 64 paths of a wavefront meet their knots at different
+// waypoints, so the wavefront runs every knot's arithmetic and the longest run of waypoints of every knot interval
+// (~50 emit rounds for 20 waypoints), twice (two 16-byte stage passes), and then copies the stage out element by
+// element: 7.8 k vector instructions per wavefront with 20 KB of LDS (two wavefronts per SIMD).
+//   Here a path lane only walks its knots ONCE for what is sequential by nature — the running arclength and the
+// running heading unwrap, in the reference's order of additions — and leaves the knots it needs for its W waypoints
+// in an LDS pool shared by the workgroup's paths (a path on a straight needs two records, one in a bend ten:
+// records are handed out by a prefix sum over the wavefront).  Then the wavefront sweeps its 16 x P x W waypoint
+// slots in memory order: a lane finds its waypoint's knot interval in the path's records, takes np.interp's slope
+// from the two knots and stores the waypoint straight from registers — every store instruction writes consecutive
+// elements, no stage, no divergence between lanes beyond the interval search.
+//   Same expressions, same bits: t_i, (q - j) / (cum_q - cum_j), slope * (t - cum_j) + j, the lane rules.
+// Vehicles with a path the pool cannot hold (more knots than SMX_WPE_KNOTS inside the kept waypoints, a pool
+// overflow) or whose team numbers its paths the long way go to a slow list and through the serial emitter of
+// k_waypoints_listed (waypoints_for: its own walks, every row, the trip meter): a serial tail inside this kernel would
+// hold its whole wavefront, and its registers would set this kernel's occupancy.
+// =================================================================================
+#define SMX_WPE_KNOTS 10  // knots after the start a path lane holds in registers
+#define SMX_WPE_POOL 384  // knot records per workgroup (64 paths; loop: 4.5 per path on average)
+struct __align__(8) WpKnot {
+  double x, y, h, cum;  // position, unwrapped heading, arclength from the projected start
+  short lane, strict;   // the knot's lane; lane of the last knot with an arclength strictly below this one's
+  int pad;
+};
+
+__device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const int block) {
+  __shared__ WpKnot pool[SMX_WPE_POOL];
+  __shared__ WpRowBook book;
+  __shared__ double hdr_step[SMX_BLOCK], hdr_D[SMX_BLOCK];
+  __shared__ unsigned short hdr_off[SMX_BLOCK];
+  __shared__ unsigned char hdr_nrec[SMX_BLOCK], hdr_n[SMX_BLOCK];
+  // lane width / speed limit / lane index of the path's start lane, and whether every knot held lies on that lane (almost
+  // always): the waypoint lanes then need no table look-up behind their interval search
+  __shared__ double hdr_w0[SMX_BLOCK], hdr_s0[SMX_BLOCK];
+  __shared__ signed char hdr_li0[SMX_BLOCK];
+  __shared__ unsigned char hdr_one_lane[SMX_BLOCK];
+  __shared__ double first_wp[SMX_WPT_VEHICLES][3];
+  static_assert(sizeof(WpKnot) == 40, "WpKnot layout");
+  const smx_config& c = a.cfg;
+  const MapDev& m = a.map;
+  const smx_outputs& o = a.out;
+  const size_t total = (size_t)c.num_envs * c.num_vehicles;
+  const int P = c.wp_paths, W = c.wp_len;
+  const int p0 = threadIdx.x % SMX_WP_LANES, v = threadIdx.x / SMX_WP_LANES;
+  const size_t gid = launch_vehicle(a, (size_t)block * SMX_WPT_VEHICLES + v, total);
+  const size_t path = gid * SMX_WP_LANES + p0, paths = total * SMX_WP_LANES;
+  const int col = threadIdx.x;
+  // Every load whose address only needs the vehicle is issued here, together and whatever the flags say (a dead slot's
+  // words are loaded and dropped): the kernel runs two wavefronts per SIMD, and flags -> seeds -> knot list -> records
+  // -> trip meter taken one after the other was five round trips of 2-4 us each under load (round 3: 85 of its 217 us).
+  constexpr int KP = SMX_WPE_KNOTS;
+  const bool in_range = gid < total;
+  const size_t g = in_range ? gid : 0, pth = g * SMX_WP_LANES + p0;
+  int flags = a.st.flags[g];
+  const int pend = a.seed_pending != nullptr ? (int)a.seed_pending[g] : 0;
+  double px = a.st.f64[(size_t)SMX_S_X * total + g], py = a.st.f64[(size_t)SMX_S_Y * total + g];
+  PathSeeds seed = load_seeds(a, g, total);
+  int n_first = a.knots.n[pth];  // what k_wp_walk found on seed lane p0 (0: no path starts there)
+  int nk = a.knots.nk[pth], cnt = a.knots.cnt[pth];
+  double D = a.knots.D[pth];
+  const int kid0 = a.knots.idx[pth];
+  int kid[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) kid[k] = a.knots.idx[(size_t)(k + 1) * paths + pth];
+  // the trip meter's words (lane 0 of the team uses them)
+  const double trip_dist = a.st.f64[(size_t)SMX_S_DIST * total + g], trip_x = a.st.f64[(size_t)SMX_S_TRIP_X * total + g],
+               trip_y = a.st.f64[(size_t)SMX_S_TRIP_Y * total + g], trip_h = a.st.f64[(size_t)SMX_S_TRIP_H * total + g];
+  const int trip_has = a.st.facts_i32[(size_t)SMX_FI_TRIP_HAS_WP * total + g];
+  // (the slow chain writes the rows of a vehicle whose seeds it is still looking for: k_scan_fast; uniform in the team)
+  const bool live = in_range && (flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST)) && !pend;
+  if (!live) {
+    seed.road = -1;
+    seed.n_lanes = 0;
+    seed.f.none();
+    n_first = nk = cnt = 0;
+    D = 0.0;
+  }
+  // ---- 1. number the paths (as the staged form does)
+  const bool seeded = live && seed.road >= 0;
+  const bool long_way = seeded && seed.n_lanes > SMX_WP_LANES;  // uniform in the team
+  int started = n_first > 0 ? (1 << p0) : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) started |= __shfl_xor(started, msk, SMX_WP_LANES);
+  const int prov = __popc(started & ((1 << p0) - 1));  // this lane's path number if nobody branches
+  int branching = (cnt > 1) ? 1 : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) branching |= __shfl_xor(branching, msk, SMX_WP_LANES);
+  const bool serial_team = seeded && (long_way || branching != 0);  // uniform in the team
+  const int n_paths_staged = __popc(started);
+  const bool staged = n_first > 0 && !serial_team;  // this lane's path leaves through the table (or the serial emitter alone)
+  const bool listed = nk <= SMX_WPK_CAP;            // ... k_wp_walk's knot list holds all its knots
+  const bool my_row = staged && prov < P;           // ... and one of the kept rows holds it
+  // ---- 2. the path lane's walk over its knots: arclength, unwrapped headings, how many it needs
+  bool tabled_path = false;
+  int nrec = 0;
+  double kx[KP], ky[KP], kh[KP], cum[KP];
+  int kl[KP], kstrict[KP];
+  double k0x = 0.0, k0y = 0.0, k0h = 0.0;
+  int lane0 = 0;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    kx[k] = ky[k] = kh[k] = cum[k] = 0.0;
+    kl[k] = kstrict[k] = 0;
+  }
+  const bool walk = my_row && listed && !SMX_SKIP(a, 1 << 22);
+  if (walk) {
+    const smx_lp_rec r0 = load_lp(m, kid0, 46);
+    lane0 = r0.lane;
+    const int nkp = nk < KP ? nk : KP;
+    {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const bool have = k < nkp;
+        const smx_lp_rec* r = m.lp_rec + (have ? kid[k] : 0);
+        kx[k] = have ? r->x : 0.0;
+        ky[k] = have ? r->y : 0.0;
+        kh[k] = have ? r->heading : 0.0;
+        kl[k] = have ? r->lane : 0;
+      }
+    }
+    const int n = n_first;
+    if (n == 1) {
+      // :1379-1390 (a one-point path): the lanepoint itself, not the projection; its heading as it is
+      k0x = r0.x;
+      k0y = r0.y;
+      k0h = r0.heading;
+      nrec = 1;
+      tabled_path = true;
+    } else {
+      const double proj = (px - r0.x) * r0.dirx + (py - r0.y) * r0.diry;
+      k0x = r0.x + proj * r0.dirx;
+      k0y = r0.y + proj * r0.diry;
+      k0h = r0.heading;
+      const int n_emit = n < W ? n : W;
+      const double step = D / (double)(n - 1);  // np.linspace(0, D, n)
+      const double t_last = (n_emit - 1 == n - 1) ? D : (double)(n_emit - 1) * step;
+      double jx = k0x, jy = k0y, jcum = 0.0;
+      int jlane = lane0, strict_lane = lane0;
+      Unwrap uw;
+      uw.start(k0h);
+      int need = -1;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (k < nkp && need < 0) {
+          const double ex = kx[k] - jx, ey = ky[k] - jy;
+          const double qcum = jcum + sqrt(ex * ex + ey * ey);
+          kh[k] = uw.push(kh[k]);
+          cum[k] = qcum;
+          if (qcum > jcum) strict_lane = jlane;
+          kstrict[k] = strict_lane;
+          if (t_last < qcum) need = k + 2;  // the last kept waypoint lies inside this interval
+          jx = kx[k];
+          jy = ky[k];
+          jcum = qcum;
+          jlane = kl[k];
+        }
+      }
+      if (need < 0 && nkp == nk) need = nk + 1;  // kept waypoints at or beyond the last knot: every knot, the last one as the tail
+      if (need > 0) {
+        nrec = need;
+        tabled_path = true;
+      }
+    }
+  }
+  // ---- records handed out by an exclusive prefix sum over the wavefront's paths
+  int incl = tabled_path ? nrec : 0;
+  {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+  }
+  const int off = incl - (tabled_path ? nrec : 0);
+  if (tabled_path && off + nrec > SMX_WPE_POOL) tabled_path = false;  // the pool is full
+  // A team with a row the pool does not hold (more knots than the table form takes, a cut knot list, a full pool), or
+  // that has to number its paths the long way (a branching inside the lookahead, a road of more than four lanes),
+  // leaves all its rows and its trip meter to k_waypoints_listed: its vehicle goes to the slow list.
+  // (so does a new vehicle, whose trip meter starts with a walk of its own: none comes here on a tick, whose new
+  // vehicles are the reset pass's)
+  int slow_i = (live && (serial_team || (my_row && !tabled_path) || (flags & SMX_F_FIRST))) ? 1 : 0;
+#pragma unroll
+  for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) slow_i |= __shfl_xor(slow_i, msk, SMX_WP_LANES);
+  const bool slow_team = slow_i != 0;  // uniform in the team
+  if (slow_team) tabled_path = false;
+  if (p0 == 0) {
+    book.veh[v] = (unsigned int)(gid < total ? gid : 0);
+    book.tabled[v] = (live && !slow_team) ? 1 : 0;
+    book.paths[v] = (unsigned char)(seeded ? n_paths_staged : 0);
+  }
+  for (int slot = p0; slot < P; slot += SMX_WP_LANES) {
+    // rows without a path read zeros; a dead / absent vehicle's rows are not this kernel's to write
+    book.src[v * P + slot] = (short)((live && !slow_team) ? SMX_ROW_ZERO : SMX_ROW_SKIP);
+    book.count[v * P + slot] = 0;
+  }
+  {
+    // the wavefront's slow vehicles, appended with one atomic
+    const bool app = slow_team && p0 == 0;
+    const unsigned long long mask = __ballot(app);
+    if (mask != 0ull) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(a.slow_count, __popcll(mask));
+      base = __shfl(base, __ffsll((long long)mask) - 1);
+      if (app) a.slow_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
+    }
+  }
+  __syncthreads();  // (one wavefront: orders the LDS writes of the team's other lanes)
+  if (my_row && !slow_team) {
+    book.src[v * P + prov] = (short)col;
+    book.count[v * P + prov] = (unsigned char)min(n_first, W);
+  }
+  if (tabled_path) {
+    hdr_step[col] = n_first > 1 ? D / (double)(n_first - 1) : 0.0;
+    hdr_D[col] = D;
+    hdr_off[col] = (unsigned short)off;
+    hdr_nrec[col] = (unsigned char)nrec;
+    hdr_n[col] = (unsigned char)n_first;
+    hdr_w0[col] = m.lane_width[lane0];
+    hdr_s0[col] = m.lane_speed[lane0];
+    hdr_li0[col] = (signed char)m.lane_index[lane0];
+    {
+      bool one = true;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) one = one && (k + 1 >= nrec || kl[k] == lane0);
+      hdr_one_lane[col] = one ? 1 : 0;
+    }
+    WpKnot r;
+    r.x = k0x;
+    r.y = k0y;
+    r.h = k0h;
+    r.cum = 0.0;
+    r.lane = (short)lane0;
+    r.strict = (short)lane0;
+    r.pad = 0;
+    pool[off] = r;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      if (k + 1 < nrec) {
+        WpKnot q;
+        q.x = kx[k];
+        q.y = ky[k];
+        q.h = kh[k];
+        q.cum = cum[k];
+        q.lane = (short)kl[k];
+        q.strict = (short)kstrict[k];
+        q.pad = 0;
+        pool[off + k + 1] = q;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. the waypoint slots of the workgroup's vehicles in memory order, a lane per waypoint
+  {
+    const int elems = SMX_WPT_VEHICLES * P * W;
+    int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per round
+    int vv = row / P, slot = row - vv * P;                 // row = vv * P + slot: team vv's path row `slot`
+    const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
+#pragma unroll 2
+    for (int e = threadIdx.x; e < (SMX_SKIP(a, 1 << 21) ? 0 : elems); e += SMX_BLOCK) {
+      const int src = book.src[row];
+      if (src != SMX_ROW_SKIP) {
+        double x = 0.0, y = 0.0;
+        float hd = 0.0f, wd = 0.0f, sp = 0.0f;
+        int ln = -1, li = 0;
+        if (src >= 0 && i < (int)book.count[row]) {
+          const int n = hdr_n[src], nr = hdr_nrec[src], koff = hdr_off[src];
+          const bool one_lane = hdr_one_lane[src] != 0;
+          const WpKnot* kn = pool + koff;
+          const double t = (i == n - 1) ? hdr_D[src] : (double)i * hdr_step[src];
+          // np.interp's interval: the last knot with cum <= t.  Cums do not decrease along the path, so that is the
+          // number of knots 1 .. nr-1 with cum <= t; the reads are issued together (a loop that stops at the first
+          // larger cum waits for one LDS round trip per knot)
+          int j = 0;
+#pragma unroll
+          for (int k = 1; k <= SMX_WPE_KNOTS; ++k) {
+            const double ck = pool[min(koff + k, SMX_WPE_POOL - 1)].cum;
+            j += (k < nr && ck <= t) ? 1 : 0;
+          }
+          const WpKnot K = kn[j];
+          double h = K.h;
+          x = K.x;
+          y = K.y;
+          double wj, sj;
+          if (one_lane) {
+            wj = hdr_w0[src];
+            sj = hdr_s0[src];
+          } else {
+            wj = m.lane_width[K.lane];
+            sj = m.lane_speed[K.lane];
+          }
+          if (j + 1 < nr) {
+            const WpKnot Q = kn[j + 1];
+            const double den = Q.cum - K.cum;
+            const double dt_ = t - K.cum;
+            const double sx = (Q.x - K.x) / den, sy = (Q.y - K.y) / den, sh = (Q.h - K.h) / den;
+            x = sx * dt_ + K.x;
+            y = sy * dt_ + K.y;
+            h = sh * dt_ + K.h;
+            if (Q.lane != K.lane) {
+              const double sw = (m.lane_width[Q.lane] - wj) / den, ss = (m.lane_speed[Q.lane] - sj) / den;
+              wj = sw * dt_ + wj;
+              sj = ss * dt_ + sj;
+            }
+          }
+          // (at or beyond the last knot: the knot itself; t == cum: the lane of the last knot strictly passed)
+          const int dl = (t == K.cum) ? (int)K.strict : (int)K.lane;
+          h = (n == 1) ? h : wrap_heading(h);
+          hd = (float)h;
+          wd = (float)wj;
+          sp = (float)sj;
+          ln = dl;
+          li = one_lane ? (int)hdr_li0[src] : m.lane_index[dl];
+          if (i == 0 && slot == 0) {  // first waypoint of the vehicle's first path: the trip meter's
+            first_wp[vv][0] = x;
+            first_wp[vv][1] = y;
+            first_wp[vv][2] = h;
+          }
+        }
+        const size_t q = ((size_t)book.veh[vv] * P + slot) * W + i;
+        if (!SMX_SKIP(a, 1 << 20) || x == 1.2345e300) {  // (developer ablation: compute, do not store)
+          double* dst = o.wp_pos + q * 3;
+          dst[0] = x;
+          dst[1] = y;
+          dst[2] = 0.0;
+          o.wp_heading[q] = hd;
+          o.wp_lane_width[q] = wd;
+          o.wp_speed_limit[q] = sp;
+          o.wp_lane_id[q] = (int16_t)ln;
+          o.wp_lane_index[q] = (int8_t)li;
+        }
+      }
+      row += drow;
+      slot += drow;
+      i += di;
+      if (i >= W) {
+        i -= W;
+        ++row;
+        ++slot;
+      }
+      while (slot >= P) {
+        slot -= P;
+        ++vv;
+      }
+    }
+    // wp_count: [vehicle][0] = number of paths, [1 + slot] = waypoints kept of the path in that row
+    const int cells = SMX_WPT_VEHICLES * (P + 1);
+    for (int e = threadIdx.x; e < cells; e += SMX_BLOCK) {
+      const int vq = e / (P + 1), qq = e - vq * (P + 1);
+      if (!book.tabled[vq]) continue;
+      o.wp_count[(size_t)book.veh[vq] * (P + 1) + qq] = qq == 0 ? book.paths[vq] : book.count[vq * P + qq - 1];
+    }
+  }
+  __syncthreads();  // first_wp is complete
+  // ---- trip meter + reward (lane 0 of the team): path 0 is the lowest started lane's, row 0 of the vehicle
+  if (live && !slow_team && p0 == 0) {
+    // trip_meter_update on the words loaded at the top (no new vehicle comes here)
+    double dist = trip_dist;
+    bool trip_has_wp = trip_has != 0;
+    const double last_dist = dist;
+    if (n_paths_staged > 0 && trip_counts_waypoint(a, m, gid, total)) {
+      const double fwx = first_wp[v][0], fwy = first_wp[v][1], fwh = first_wp[v][2];
+      if (!trip_has_wp) {
+        SF(SMX_S_TRIP_X) = fwx;
+        SF(SMX_S_TRIP_Y) = fwy;
+        SF(SMX_S_TRIP_H) = fwh;
+        trip_has_wp = true;
+      } else {
+        const double dx = fwx - trip_x, dy = fwy - trip_y;
+        const double nrm = sqrt(dx * dx + dy * dy);
+        if (nrm > 0.5) {
+          double hvx, hvy;
+          radians_to_vec(trip_h, hvx, hvy);
+          const double dot = hvx * dx + hvy * dy;
+          const double sgn = dot > 0.0 ? 1.0 : (dot < 0.0 ? -1.0 : 0.0);
+          dist += sgn * nrm;
+          SF(SMX_S_TRIP_X) = fwx;
+          SF(SMX_S_TRIP_Y) = fwy;
+          SF(SMX_S_TRIP_H) = fwh;
+        }
+      }
+    }
+    SF(SMX_S_DIST) = dist;
+    o.dist[gid] = dist;
+    if (!a.keep_reward_done) {
+      o.reward[gid] = dist - last_dist;
+      if (o.learner) o.learner[gid] = (float)(dist - last_dist);
+    }
+    a.st.facts_i32[(size_t)SMX_FI_TRIP_HAS_WP * total + gid] = trip_has_wp ? 1 : 0;
+  }
 }
 
 // =================================================================================
@@ -2926,8 +3660,10 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
         const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
         const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
         // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
-        int c0 = (int)floor((cx - ext_x) * inv_res + 0.5 * W - 0.5) - 1, c1 = (int)ceil((cx + ext_x) * inv_res + 0.5 * W - 0.5) + 1;
-        int r0 = (int)floor(0.5 * H - 0.5 - (cy + ext_y) * inv_res) - 1, r1 = (int)ceil(0.5 * H - 0.5 - (cy - ext_y) * inv_res) + 1;
+        // (a pixel centre inside the footprint lies inside its bounding box: columns ceil(lo) .. floor(hi); one more
+        // on every side covers the rounding of these bounds — two more only grew the rectangles into a second 8 x 8 block)
+        int c0 = (int)ceil((cx - ext_x) * inv_res + 0.5 * W - 0.5) - 1, c1 = (int)floor((cx + ext_x) * inv_res + 0.5 * W - 0.5) + 1;
+        int r0 = (int)ceil(0.5 * H - 0.5 - (cy + ext_y) * inv_res) - 1, r1 = (int)floor(0.5 * H - 0.5 - (cy - ext_y) * inv_res) + 1;
         c0 = max(c0, 0);
         r0 = max(r0, 0);
         c1 = min(c1, W - 1);
@@ -3414,6 +4150,16 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_grid_first(const KernelArgs a) {
 }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_tables(const KernelArgs a) { waypoints_tables_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_emit(const KernelArgs a) { waypoints_emit_role(a, (int)blockIdx.x); }
+// the vehicles k_waypoints_emit left on the slow list: waypoints_for (a team of four lanes per vehicle), a fixed grid
+// striding the list, whose length is only known on the device
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_listed(const KernelArgs a) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  const int count = *a.slow_count;
+  constexpr int VPB = SMX_BLOCK / SMX_WP_LANES;
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
+    waypoints_for<SMX_BLOCK>(a, (size_t)a.slow_list[i], knot_scratch + threadIdx.x);
+}
 // (capped at 168 registers for a third wavefront per SIMD beside the waypoint kernels it spills 52 of them: 0.796 -> 0.806 ms)
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
@@ -3496,7 +4242,8 @@ struct smx_handle_s {
   size_t map_bytes;
   void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
   int32_t* alive_blob;  // [total] alive list + two counters (ticks alternate), large batches
-  int32_t* slow_blob;   // [2][total] slow lists of the one-lane scan kernels (facts, seeds) + their 2 x 2 counters (ticks alternate)
+  uint8_t* pending_blob;  // [total] seed_pending
+  int32_t* slow_blob;   // [4][total] slow lists of the fast kernels (scan facts, scan seeds, control, waypoint rows) + [2][4] counters (ticks alternate)
   double* scan_carry;   // [6][total]: seeds_carry (x, y, d10^2, d1^2) | facts_carry (x, y) of the seeded scan
   int alive_parity;
   KnotLists knots;
@@ -3506,8 +4253,8 @@ struct smx_handle_s {
   // Large batches: the sensor kernels of a tick are independent of each other (they read the pose and write
   // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
   // their own write stream — so they are enqueued on side streams between two events and overlap.
-  hipStream_t side[2];
-  hipEvent_t ev_fork, ev_fork_grid, ev_join[2];
+  hipStream_t side[3];
+  hipEvent_t ev_fork, ev_fork_grid, ev_fork_slow, ev_join[3];
   bool side_ready;
   const double* lidar_rays;
   smx_via* vias_dev;
@@ -3592,6 +4339,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->alive_blob = nullptr;
   h->scan_carry = nullptr;
   h->slow_blob = nullptr;
+  h->pending_blob = nullptr;
   h->alive_parity = 0;
   h->knots = KnotLists{};
   h->ctrl_blob = nullptr;
@@ -3814,9 +4562,14 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     SMX_HIP(hipMemset(h->alive_blob, 0, n * sizeof(int32_t)));
   }
   if (!h->slow_blob) {
-    const size_t n = 2 * (size_t)h->cfg.num_envs * h->cfg.num_vehicles + 4;
+    const size_t n = 4 * (size_t)h->cfg.num_envs * h->cfg.num_vehicles + 8;
     SMX_HIP(hipMalloc((void**)&h->slow_blob, n * sizeof(int32_t)));
     SMX_HIP(hipMemset(h->slow_blob, 0, n * sizeof(int32_t)));
+  }
+  if (!h->pending_blob) {
+    const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+    SMX_HIP(hipMalloc((void**)&h->pending_blob, n));
+    SMX_HIP(hipMemset(h->pending_blob, 0, n));
   }
   if (!h->scan_carry) {  // all ones = NaN: nothing to start a seeded search from yet
     const size_t n = 6 * (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
@@ -3861,11 +4614,12 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     // the side kernels fill the chip around it instead of sharing it evenly
     int prio_least = 0, prio_greatest = 0;
     SMX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
       SMX_HIP(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, prio_least));
       SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    SMX_HIP(hipEventCreateWithFlags(&h->ev_fork_slow, hipEventDisableTiming));
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork_grid, hipEventDisableTiming));
     h->side_ready = true;
   }
@@ -4177,6 +4931,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   a.slow_list = nullptr;
   a.slow_count = nullptr;
+  a.seed_pending = nullptr;
   a.seeds_carry = h->scan_carry;
   a.facts_carry = h->scan_carry ? h->scan_carry + 4 * total : nullptr;
   const int veh_blocks = (int)((total + SMX_BLOCK - 1) / SMX_BLOCK);
@@ -4251,6 +5006,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     // the caller's stream; all are joined before k_commit.
     const bool fork = !small_batch && !phased && h->side_ready;
     hipStream_t s_grid = stream, s_obs = stream;
+    KernelArgs kf = k, ks = k, kwp = k;  // (kwp: the waypoint kernels, which pass over the slow chain's vehicles)
+    bool slow_chain_forked = false, slow_chain_pending = false;
     if (fork) {
       (void)hipEventRecord(h->ev_fork_grid, stream);
       (void)hipStreamWaitEvent(h->side[0], h->ev_fork_grid, 0);
@@ -4266,19 +5023,32 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
       const bool fast = fast_scan && k.alive_list != nullptr && !k.first_only && h->slow_blob && !SMX_SCAN_UNSEEDED;
       const unsigned fast_blocks = (unsigned)((total + SMX_BLOCK - 1) / SMX_BLOCK);
-      KernelArgs kf = k, ks = k;  // facts / seeds: each half appends to its own slow list
+      kf = k;
+      ks = k;  // facts / seeds: each half appends to its own slow list
       if (fast) {
-        int32_t* slow_counters = h->slow_blob + 2 * total + 2 * slow_parity;
+        int32_t* slow_counters = h->slow_blob + 4 * total + 4 * slow_parity;
         kf.slow_list = h->slow_blob;
         kf.slow_count = slow_counters;
         ks.slow_list = h->slow_blob + total;
         ks.slow_count = slow_counters + 1;
       }
       // path seeds without the ten-nearest list: agents with a route object and no fixed route, waypoints sensor on
-      const bool fast_seeds = fast && !routed && (c.sensors & SMX_SENSOR_WAYPOINTS);
+      const bool fast_seeds = !SMX_WP_STAGED && fast && !routed && (c.sensors & SMX_SENSOR_WAYPOINTS) && h->pending_blob;
       if (fast_seeds) {
+        ks.seed_pending = h->pending_blob;
+        kwp.seed_pending = h->pending_blob;
         hipLaunchKernelGGL(k_scan_fast<1>, dim3(fast_blocks), dim3(SMX_BLOCK), 0, stream, ks);
-        hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+        if (fork) {
+          // the slow chain — the few vehicles whose seeds take the searches from scratch, then their walks and rows by the
+          // serial emitter — runs beside the main chain (k_wp_walk -> k_waypoints_emit pass over those vehicles)
+          (void)hipEventRecord(h->ev_fork_slow, stream);
+          (void)hipStreamWaitEvent(h->side[2], h->ev_fork_slow, 0);
+          hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          slow_chain_forked = true;
+        } else {
+          slow_chain_pending = true;  // (one stream: after the main waypoint kernels, below)
+        }
       } else if (routed)
         hipLaunchKernelGGL((k_scan_half<1, true>), dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
       else
@@ -4324,9 +5094,27 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     } else {
       // staged rows whenever the waypoints sensor is on and the rows fit that form
       if ((c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS && h->knots_blob) {
-        hipLaunchKernelGGL(k_wp_walk, dim3((unsigned)((total * SMX_WP_LANES + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0, stream, k);
+        hipLaunchKernelGGL(k_wp_walk, dim3((unsigned)((total * SMX_WP_LANES + SMX_BLOCK - 1) / SMX_BLOCK)), dim3(SMX_BLOCK), 0, stream, kwp);
+#if SMX_WP_STAGED  // developer variant: round 2's staged rows
         const size_t stage_bytes = std::max((size_t)c.wp_len * SMX_BLOCK * 16, (size_t)SMX_MAX_KNOTS * SMX_BLOCK * sizeof(int));
         hipLaunchKernelGGL(k_waypoints_tables, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, k);
+#else
+        if (fast_scan && k.alive_list != nullptr && h->slow_blob) {
+          KernelArgs kw = kwp;
+          kw.slow_list = h->slow_blob + 3 * total;
+          kw.slow_count = h->slow_blob + 4 * total + 4 * slow_parity + 3;
+          hipLaunchKernelGGL(k_waypoints_emit, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, kw);
+          hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, kw);
+          if (slow_chain_pending) {
+            hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+            hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+            slow_chain_pending = false;
+          }
+        } else {
+          const size_t stage_bytes = std::max((size_t)c.wp_len * SMX_BLOCK * 16, (size_t)SMX_MAX_KNOTS * SMX_BLOCK * sizeof(int));
+          hipLaunchKernelGGL(k_waypoints_tables, dim3(wp_blocks), dim3(SMX_BLOCK), stage_bytes, stream, k);
+        }
+#endif
       } else
         hipLaunchKernelGGL(k_waypoints, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, k);
       hipLaunchKernelGGL(k_observe, dim3(obs_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
@@ -4335,7 +5123,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     if (fork) {
       // (each side stream joins the caller's directly: chaining side 0 through side 1 puts one more hop behind the
       // last kernel when k_observe ends the tick — 1 % late in a run)
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < (slow_chain_forked ? 3 : 2); ++i) {
         (void)hipEventRecord(h->ev_join[i], h->side[i]);
         (void)hipStreamWaitEvent(stream, h->ev_join[i], 0);
       }
@@ -4354,9 +5142,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   const bool two_launch_control = is_step && !small_batch && h->ctrl_blob;
   if (is_step && !small_batch && h->alive_blob) {
     int32_t* counters = h->alive_blob + total;
-    int32_t* slow_counters = h->slow_blob + 2 * total;  // [parity][role]
+    int32_t* slow_counters = h->slow_blob + 4 * total;  // [parity][4]: facts, seeds, control, waypoint rows
     hipLaunchKernelGGL(k_alive_list, dim3((unsigned)((total + SMX_ALIVE_BLOCK - 1) / SMX_ALIVE_BLOCK)), dim3(SMX_ALIVE_BLOCK), 0, stream, a, h->alive_blob, counters + h->alive_parity,
-                       counters + (h->alive_parity ^ 1), slow_counters + 2 * (h->alive_parity ^ 1));
+                       counters + (h->alive_parity ^ 1), slow_counters + 4 * (h->alive_parity ^ 1));
     a.alive_list = h->alive_blob;
     a.alive_count = counters + h->alive_parity;
     fast_scan = true;
@@ -4366,14 +5154,31 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   if (two_launch_control) {
     // large batches: candidate paths by teams of four, then law + physics with one lane per vehicle
     const CtrlHandoff ho = h->ctrl;
+    KernelArgs ac = a;  // the controller's slow list
+    if (fast_scan && h->slow_blob) {
+      ac.slow_list = h->slow_blob + 2 * total;
+      ac.slow_count = h->slow_blob + 4 * total + 4 * slow_parity + 2;
+    }
     switch (c.action_space) {
       case SMX_ACTION_SPACE_LANE:
-        hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
-        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        if (fast_scan && h->slow_blob) {  // one lane per vehicle; the rest through the slow list (k_control_fast)
+          hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+        } else {
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        }
         break;
       case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
-        hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
-        hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        if (fast_scan && h->slow_blob) {
+          hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+        } else {
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
+        }
         break;
       case SMX_ACTION_SPACE_CONTINUOUS:
         hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_CONTINUOUS>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
@@ -4550,15 +5355,17 @@ extern "C" void smx_destroy(smx_handle h) {
   if (h->alive_blob) (void)hipFree(h->alive_blob);
   if (h->scan_carry) (void)hipFree(h->scan_carry);
   if (h->slow_blob) (void)hipFree(h->slow_blob);
+  if (h->pending_blob) (void)hipFree(h->pending_blob);
   if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
   if (h->status_dev) (void)hipFree(h->status_dev);
   if (h->side_ready) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
       (void)hipStreamSynchronize(h->side[i]);
       (void)hipStreamDestroy(h->side[i]);
       (void)hipEventDestroy(h->ev_join[i]);
     }
     (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_fork_slow);
     (void)hipEventDestroy(h->ev_fork_grid);
   }
   if (h->vias_dev) (void)hipFree(h->vias_dev);

@@ -912,7 +912,46 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
 // ---------------------------------------------------------------------------------
 #define SMX_FACTS_CAND 24  // survivors kept per vehicle (3 lanes x 1-2 segments typically)
 
+// Two positions along a lane's centre line (position_at_shape_offset, utils/math.py:319-331, for offsets s <= e),
+// searching from vertex `vfrom` (cum[vfrom] <= s): five vertex records are loaded together, which covers the common
+// case (both offsets within four segments of vfrom); otherwise the walk of team_position_at_shape_offset.
+__device__ inline void lane_positions_at_offsets(const MapDev& m, int v0, int v1, int vfrom, double s_off, double e_off,
+                                                 double& p1x, double& p1y, double& p2x, double& p2y) {
+  smx_shape_rec r[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) r[u] = m.shape_rec[min(vfrom + u, v1 - 1)];
+  int hs = -1, he = -1;
+#pragma unroll
+  for (int u = 3; u >= 0; --u) {
+    const bool seg = vfrom + u + 1 < v1;  // vertex vfrom + u starts a segment
+    if (seg && r[u].cum + r[u].len > s_off) hs = u;
+    if (seg && r[u].cum + r[u].len > e_off) he = u;
+  }
+  // (the first hit: a later iteration of the descending loop overwrites a later hit with an earlier one)
+  auto at = [&](int u, double off, double& ox, double& oy) {
+    smx_shape_rec a = r[0], b2 = r[1];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (u == q) {
+        a = r[q];
+        b2 = r[q + 1];
+      }
+    position_at_offset(a.x, a.y, b2.x, b2.y, a.len, off - a.cum, ox, oy);
+  };
+  if (hs >= 0)
+    at(hs, s_off, p1x, p1y);
+  else
+    team_position_at_shape_offset<1>(m, v0, v1, s_off, p1x, p1y, vfrom);
+  if (he >= 0)
+    at(he, e_off, p2x, p2y);
+  else
+    team_position_at_shape_offset<1>(m, v0, v1, e_off, p2x, p2y, vfrom);
+}
+
 // `cand`: this lane's column of an LDS array [SMX_FACTS_CAND][stride] of record indices.
+// Loads come in batches of four records (the kernel runs two wavefronts per SIMD and every dependent load is a
+// microsecond under load): the rows' offsets together, then the grid records, then the survivors.
+#define SMX_FACTS_SPAN 4  // grid rows the seeded visit handles (a reach of ~4 m over 8 m cells meets two, seldom three)
 __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, double pose_radius, int n_corners,
                                       const double* cx, const double* cy, const FactsCarry& c, double thr_max, int* cand,
                                       int stride, bool want_heading, RoadFacts& out, double& lane_heading) {
@@ -928,27 +967,57 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
   cy0 = max(cy0, 0);
   cx1 = min(cx1, m.sg_nx - 1);
   cy1 = min(cy1, m.sg_ny - 1);
+  if (cx0 > cx1 || cy0 > cy1 || cy1 - cy0 >= SMX_FACTS_SPAN) return false;
   // ---- pass 1: records whose bounding box can matter to the centre (nearest lane within the bound, or its
   // road_with_point threshold) or to a corner (threshold + half a vehicle diagonal)
+  int ra[SMX_FACTS_SPAN], rn[SMX_FACTS_SPAN];
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < SMX_FACTS_SPAN; ++i) {
+    const int y = cy0 + i;
+    const bool in = y <= cy1;
+    const int row = (in ? y : cy0) * m.sg_nx;
+    const int va = m.sg_off[row + cx0], vb = m.sg_off[row + cx1 + 1];
+    ra[i] = va;
+    total += in ? vb - va : 0;
+    rn[i] = total;
+  }
+  auto member = [&](int q) {
+    int k = ra[0] + q;
+#pragma unroll
+    for (int i = 1; i < SMX_FACTS_SPAN; ++i)
+      if (q >= rn[i - 1]) k = ra[i] + (q - rn[i - 1]);
+    return k;
+  };
   int n = 0;
   bool overflow = false;
-  if (cx0 <= cx1) {
-    for (int gy = cy0; gy <= cy1; ++gy) {
-      const int row = gy * m.sg_nx;
-      const int a = m.sg_off[row + cx0], b = m.sg_off[row + cx1 + 1];
-      for (int k = a; k < b; ++k) {
-        const smx_seg_rec* s = m.sg_rec + k;
-        const double x1 = s->x1, y1 = s->y1, x2 = s->x2, y2 = s->y2, thr = s->thr;
-        const double gx = fmax(fmax(fmin(x1, x2) - px, px - fmax(x1, x2)), 0.0);
-        const double gy2 = fmax(fmax(fmin(y1, y2) - py, py - fmax(y1, y2)), 0.0);
-        const double keep_c = fmin(fmax(dist_bound, thr), radius) + 3e-6;
-        const double keep = n_corners > 0 ? fmax(keep_c, thr + 2.0 + 1e-6) : keep_c;
-        if (gx * gx + gy2 * gy2 > keep * keep) continue;
-        if (n < SMX_FACTS_CAND)
-          cand[n * stride] = k;
-        else
-          overflow = true;
-        ++n;
+  for (int q0 = 0; q0 < total; q0 += 4) {
+    double x1[4], y1[4], x2[4], y2[4], thr[4];
+    int kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      kk[u] = member(q0 + u < total ? q0 + u : 0);
+      const smx_seg_rec* r = m.sg_rec + kk[u];
+      x1[u] = r->x1;
+      y1[u] = r->y1;
+      x2[u] = r->x2;
+      y2[u] = r->y2;
+      thr[u] = r->thr;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q0 + u < total) {
+        const double gx = fmax(fmax(fmin(x1[u], x2[u]) - px, px - fmax(x1[u], x2[u])), 0.0);
+        const double gy2 = fmax(fmax(fmin(y1[u], y2[u]) - py, py - fmax(y1[u], y2[u])), 0.0);
+        const double keep_c = fmin(fmax(dist_bound, thr[u]), radius) + 3e-6;
+        const double keep = n_corners > 0 ? fmax(keep_c, thr[u] + 2.0 + 1e-6) : keep_c;
+        if (!(gx * gx + gy2 * gy2 > keep * keep)) {
+          if (n < SMX_FACTS_CAND)
+            cand[n * stride] = kk[u];
+          else
+            overflow = true;
+          ++n;
+        }
       }
     }
   }
@@ -959,104 +1028,159 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
   out.on_road = false;
   out.corner_mask = 0;
   int lane_key = 0x7fffffff;
-  for (int i = 0; i < n; ++i) {
-    const smx_seg_rec s = m.sg_rec[cand[i * stride]];
-    const double ex = s.x1 - s.x2, ey = s.y1 - s.y2;
-    const double d = sqrt(ex * ex + ey * ey);
-    const double dd = d * d;
-    const double sx = s.x2 - s.x1, sy = s.y2 - s.y1;
-    auto dist_to = [&](double qx, double qy) {
-      const double u = ((qx - s.x1) * sx) + ((qy - s.y1) * sy);
-      double offset;
-      if (d == 0.0 || u < 0.0 || u > dd) {
-        offset = (u < 0.0) ? 0.0 : d;
-      } else {
-        offset = u / d;
-      }
-      if (offset == 0.0) {
-        const double fx = qx - s.x1, fy = qy - s.y1;
-        return sqrt(fx * fx + fy * fy);
-      }
-      const double uu = offset / d;
-      const double ix = s.x1 + uu * sx, iy = s.y1 + uu * sy;
-      const double fx = qx - ix, fy = qy - iy;
-      return sqrt(fx * fx + fy * fy);
-    };
-    {
-      const double dist = dist_to(px, py);
-      if (dist < radius) {
-        if (dist < out.dist || (dist == out.dist && s.lane < lane_key)) {
-          out.dist = dist;
-          lane_key = s.lane;
-        }
-        if (dist < road_radius && dist < s.thr) out.on_road = true;
-      }
+#if defined(SMX_ABLATE)  // developer timing variants: pieces switched off (results are then wrong)
+  if ((SMX_ABLATE) & (1 << 24)) {
+    out.lane = n > 0 ? m.sg_rec[cand[0]].lane : -1;
+    out.dist = (double)n;
+    lane_heading = 0.0;
+    return true;
+  }
+#endif
+  for (int i0 = 0; i0 < n; i0 += 4) {
+    double x1[4], y1[4], x2[4], y2[4], thr[4];
+    int ln[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const smx_seg_rec* r = m.sg_rec + cand[(i0 + u < n ? i0 + u : i0) * stride];
+      x1[u] = r->x1;
+      y1[u] = r->y1;
+      x2[u] = r->x2;
+      y2[u] = r->y2;
+      thr[u] = r->thr;
+      ln[u] = r->lane;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // a corner that already lies on a road has nothing more to learn
-      if (q < n_corners && !(out.corner_mask & (1 << q))) {
-        const double dist = dist_to(q == 0 ? cx[0] : (q == 1 ? cx[1] : (q == 2 ? cx[2] : cx[3])),
-                                    q == 0 ? cy[0] : (q == 1 ? cy[1] : (q == 2 ? cy[2] : cy[3])));
-        if (dist < road_radius && dist < s.thr) out.corner_mask |= (1 << q);
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u < n) {
+        const double sx1 = x1[u], sy1 = y1[u], sx2 = x2[u], sy2 = y2[u];
+        const double ex = sx1 - sx2, ey = sy1 - sy2;
+        const double d = sqrt(ex * ex + ey * ey);
+        const double dd = d * d;
+        const double sx = sx2 - sx1, sy = sy2 - sy1;
+        auto dist_to = [&](double qx, double qy) {
+          const double uq = ((qx - sx1) * sx) + ((qy - sy1) * sy);
+          double offset;
+          if (d == 0.0 || uq < 0.0 || uq > dd) {
+            offset = (uq < 0.0) ? 0.0 : d;
+          } else {
+            offset = uq / d;
+          }
+          if (offset == 0.0) {
+            const double fx = qx - sx1, fy = qy - sy1;
+            return sqrt(fx * fx + fy * fy);
+          }
+          const double uu = offset / d;
+          const double ix = sx1 + uu * sx, iy = sy1 + uu * sy;
+          const double fx = qx - ix, fy = qy - iy;
+          return sqrt(fx * fx + fy * fy);
+        };
+        {
+          const double dist = dist_to(px, py);
+          if (dist < radius) {
+            if (dist < out.dist || (dist == out.dist && ln[u] < lane_key)) {
+              out.dist = dist;
+              lane_key = ln[u];
+            }
+            if (dist < road_radius && dist < thr[u]) out.on_road = true;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // a corner that already lies on a road has nothing more to learn
+          if (q < n_corners && !(out.corner_mask & (1 << q))) {
+            const double dist = dist_to(q == 0 ? cx[0] : (q == 1 ? cx[1] : (q == 2 ? cx[2] : cx[3])),
+                                        q == 0 ? cy[0] : (q == 1 ? cy[1] : (q == 2 ? cy[2] : cy[3])));
+            if (dist < road_radius && dist < thr[u]) out.corner_mask |= (1 << q);
+          }
+        }
       }
     }
   }
   out.lane = lane_key == 0x7fffffff ? -1 : lane_key;
   lane_heading = 0.0;
+#if defined(SMX_ABLATE)
+  if ((SMX_ABLATE) & (1 << 25)) return true;
+#endif
   if (!want_heading || out.lane < 0 || m.lane_in_junction[out.lane]) return true;
   // ---- the lane heading at the nearest point of the nearest lane (team_lane_heading_at_point): its candidate
   // segments — bounding box within the lane's distance — are among the survivors of pass 1
   const int lane = out.lane;
   const int v0 = m.lane_shape_off[lane], v1 = m.lane_shape_off[lane + 1];
+  const double lane_len = m.lane_length[lane];
   int vertex_hit = 0x7fffffff;
-  double min_dist = SMX_INF, offset = -1.0;
+  double hit_cum = 0.0;
+  double min_dist = SMX_INF, offset = -1.0, near_cum = 0.0;
   int min_v = 0x7fffffff;
-  for (int i = 0; i < n; ++i) {
-    const smx_seg_rec s = m.sg_rec[cand[i * stride]];
-    if (s.lane != lane) continue;
-    if (s.x1 == px && s.y1 == py) vertex_hit = min(vertex_hit, s.v0);
-    if (s.x2 == px && s.y2 == py) vertex_hit = min(vertex_hit, s.v0 + 1);
-    {
-      const double gx = fmax(fmax(fmin(s.x1, s.x2) - px, px - fmax(s.x1, s.x2)), 0.0);
-      const double gy2 = fmax(fmax(fmin(s.y1, s.y2) - py, py - fmax(s.y1, s.y2)), 0.0);
-      const double keep = fmin(min_dist, out.dist) + 1e-6;
-      if (gx * gx + gy2 * gy2 > keep * keep) continue;
+  for (int i0 = 0; i0 < n; i0 += 4) {
+    double x1[4], y1[4], x2[4], y2[4], sl[4], sc[4];
+    int ln[4], sv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const smx_seg_rec* r = m.sg_rec + cand[(i0 + u < n ? i0 + u : i0) * stride];
+      x1[u] = r->x1;
+      y1[u] = r->y1;
+      x2[u] = r->x2;
+      y2[u] = r->y2;
+      sl[u] = r->len;
+      sc[u] = r->cum;
+      ln[u] = r->lane;
+      sv[u] = r->v0;
     }
-    const smx_shape_rec a = m.shape_rec[s.v0];
-    const double d = a.len;
-    const double u = ((px - s.x1) * (s.x2 - s.x1)) + ((py - s.y1) * (s.y2 - s.y1));
-    const double poff = (d == 0.0 || u < 0.0 || u > d * d) ? ((u < 0.0) ? 0.0 : d) : u / d;
-    double fx, fy;
-    position_at_offset(s.x1, s.y1, s.x2, s.y2, d, poff, fx, fy);
-    const double dist = euclid(px, py, fx, fy);
-    if (dist < min_dist || (dist == min_dist && s.v0 < min_v)) {
-      min_dist = dist;
-      offset = poff + a.cum;
-      min_v = s.v0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u < n && ln[u] == lane) {
+        // a vertex that equals the point wins (the first such vertex): its arclength is the segment's, or the
+        // segment's end (the same sum the vertex table holds: cum + len, added vertex by vertex on the host)
+        if (x1[u] == px && y1[u] == py && sv[u] < vertex_hit) {
+          vertex_hit = sv[u];
+          hit_cum = sc[u];
+        }
+        if (x2[u] == px && y2[u] == py && sv[u] + 1 < vertex_hit) {
+          vertex_hit = sv[u] + 1;
+          hit_cum = sc[u] + sl[u];
+        }
+        const double gx = fmax(fmax(fmin(x1[u], x2[u]) - px, px - fmax(x1[u], x2[u])), 0.0);
+        const double gy2 = fmax(fmax(fmin(y1[u], y2[u]) - py, py - fmax(y1[u], y2[u])), 0.0);
+        const double keep = fmin(min_dist, out.dist) + 1e-6;
+        if (!(gx * gx + gy2 * gy2 > keep * keep)) {
+          const double d = sl[u];
+          const double uq = ((px - x1[u]) * (x2[u] - x1[u])) + ((py - y1[u]) * (y2[u] - y1[u]));
+          const double poff = (d == 0.0 || uq < 0.0 || uq > d * d) ? ((uq < 0.0) ? 0.0 : d) : uq / d;
+          double fx, fy;
+          position_at_offset(x1[u], y1[u], x2[u], y2[u], d, poff, fx, fy);
+          const double dist = euclid(px, py, fx, fy);
+          if (dist < min_dist || (dist == min_dist && sv[u] < min_v)) {
+            min_dist = dist;
+            offset = poff + sc[u];
+            min_v = sv[u];
+            near_cum = sc[u];
+          }
+        }
+      }
     }
   }
   int v_near = v0;
+  double v_near_cum = 0.0;  // cum of the lane's first vertex
   if (vertex_hit != 0x7fffffff) {
-    offset = m.shape_rec[vertex_hit].cum;
+    offset = hit_cum;
     v_near = vertex_hit;
+    v_near_cum = hit_cum;
   } else if (min_v != 0x7fffffff) {
     v_near = min_v;
+    v_near_cum = near_cum;
   }
-  const double L = m.lane_length[lane];
   double s_off, e_off;
-  if (offset >= L) {
-    s_off = L - 1.0;
-    e_off = L;
+  if (offset >= lane_len) {
+    s_off = lane_len - 1.0;
+    e_off = lane_len;
   } else {
     s_off = offset;
     e_off = offset + 1.0;
   }
   s_off = fmax(s_off, 0.0);
   double p1x, p1y, p2x, p2y;
-  const int vfrom = (m.shape_rec[v_near].cum <= s_off) ? v_near : v0;
-  team_position_at_shape_offset<1>(m, v0, v1, s_off, p1x, p1y, vfrom);
-  team_position_at_shape_offset<1>(m, v0, v1, e_off, p2x, p2y, vfrom);
+  const int vfrom = (v_near_cum <= s_off) ? v_near : v0;
+  lane_positions_at_offsets(m, v0, v1, vfrom, s_off, e_off, p1x, p1y, p2x, p2y);
   const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
   const double half = ang * 0.5;
   const double qz = sin(half), qw = cos(half);
@@ -1078,53 +1202,67 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
 // survivors d2 <= the a-priori T into a per-lane LDS list), pass 2 scores the survivors.
 // ---------------------------------------------------------------------------------
 #define SMX_SEEDS_CAND 20
-struct ClosePick {  // running minimum of (score, d2, index)
+struct ClosePick {  // running minimum of (score, d2, index); the winner's lane rides along
   double score, d2;
-  int idx;
+  int idx, lane;
   __device__ __forceinline__ void none() {
     score = d2 = SMX_INF;
     idx = -1;
+    lane = 0;
   }
-  __device__ __forceinline__ void offer(double sc, double q2, int i) {
+  __device__ __forceinline__ void offer(double sc, double q2, int i, int ln) {
     if (sc < score || (sc == score && (q2 < d2 || (q2 == d2 && i < idx)))) {
       score = sc;
       d2 = q2;
       idx = i;
+      lane = ln;
     }
   }
 };
 
 // Returns false when the vehicle has to take the ten-nearest form (no usable carry, a list overflow, more than ten
-// members in C, a reach beyond the seeded span, the closest lanepoint on a junction road).  `d1sq`: d2 of the nearest lanepoint (for the next tick's carry).
+// members in C, a reach beyond the seeded span, the closest lanepoint on a junction road, a seed road other than last
+// tick's).  `d1sq`: d2 of the nearest lanepoint (for the next tick's carry).
+// Loads come in batches (the kernel runs two wavefronts per SIMD, every dependent load is a microsecond under load):
+// the four start records together, the rows' offsets together, the grid members eight at a time, the survivors'
+// lanepoint records four at a time.
+#define SMX_SEEDS_BATCH 8
 __device__ inline bool seeds_one_lane(const MapDev& m, double px, double py, double heading, double within_radius,
                                       const SeedsCarry& c, int* cand, int stride, PathSeeds& s, double& d1sq) {
   if (!(c.valid && c.d1 >= 0.0 && c.d1 < 1.0e290 && c.qx == c.qx && c.qy == c.qy)) return false;
   const double b = (sqrt(c.d1) + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;  // d(nearest) now is at most this
   const double t_pre = (b * b + SMX_PI) * (1.0 + 1e-12) + 1e-9;                       // ... and T at most this
   double reach = sqrt(t_pre) * (1.0 + 1e-12) + 1e-9;
-  // the road the paths started on last tick: its lanes' nearest lanepoints ride along (a guess, checked below)
-  int k0 = -9, k1 = -9, k2 = -9, k3 = -9, nk = 0;
-  if (c.prev_road >= 0 && c.prev_lanes >= 1) {
-    nk = min(c.prev_lanes, SMX_SEED_LANES);
-    const int la = m.road_lane_off[c.prev_road];
-    k0 = m.road_lanes[la];
-    k1 = nk > 1 ? m.road_lanes[la + 1] : -9;
-    k2 = nk > 2 ? m.road_lanes[la + 2] : -9;
-    k3 = nk > 3 ? m.road_lanes[la + 3] : -9;
-    bool all = true;
+  // the road the paths started on last tick: its lanes' nearest lanepoints ride along (a guess, checked below).  Lane
+  // q's key is the lane of last tick's start lanepoint q (the nearest lanepoint ON lane q of that road).
+  int kq[4] = {-9, -9, -9, -9};
+  int nk = 0;
+  {
+    double sx[4], sy[4];
+    int sl[4];
 #pragma unroll
     for (int q = 0; q < SMX_SEED_LANES; ++q) {
-      const int st = c.prev_start[q];
-      if (q < nk) {
-        if (st >= 0) {
-          const smx_lp_rec* r = m.lp_rec + st;
-          reach = fmax(reach, euclid(px, py, r->x, r->y) * (1.0 + 1e-12) + 1e-9);
-        } else {
-          all = false;
+      const smx_lp_rec* r = m.lp_rec + (c.prev_start[q] >= 0 ? c.prev_start[q] : 0);
+      sx[q] = r->x;
+      sy[q] = r->y;
+      sl[q] = r->lane;
+    }
+    if (c.prev_road >= 0 && c.prev_lanes >= 1) {
+      nk = min(c.prev_lanes, SMX_SEED_LANES);
+      bool all = true;
+#pragma unroll
+      for (int q = 0; q < SMX_SEED_LANES; ++q) {
+        if (q < nk) {
+          if (c.prev_start[q] >= 0) {
+            kq[q] = sl[q];
+            reach = fmax(reach, euclid(px, py, sx[q], sy[q]) * (1.0 + 1e-12) + 1e-9);
+          } else {
+            all = false;
+          }
         }
       }
+      if (!all) nk = 0;
     }
-    if (!all) nk = 0;
   }
   int cx0 = (int)floor((px - reach - m.lpg_x0) / m.lpg_cell), cx1 = (int)floor((px + reach - m.lpg_x0) / m.lpg_cell);
   int cy0 = (int)floor((py - reach - m.lpg_y0) / m.lpg_cell), cy1 = (int)floor((py + reach - m.lpg_y0) / m.lpg_cell);
@@ -1159,7 +1297,7 @@ __device__ inline bool seeds_one_lane(const MapDev& m, double px, double py, dou
   int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   int n = 0;
   bool overflow = false;
-  auto take = [&](const smx_pt_rec& p, int k) {
+  auto take = [&](const smx_pt_rec& p) {
     const double dx = p.x - px, dy = p.y - py;
     const double d2 = dx * dx + dy * dy;
     if (d2 < g2 || (d2 == g2 && p.idx < gi)) {
@@ -1168,81 +1306,83 @@ __device__ inline bool seeds_one_lane(const MapDev& m, double px, double py, dou
     }
     if (d2 <= t_pre) {
       if (n < SMX_SEEDS_CAND)
-        cand[n * stride] = k;
+        cand[n * stride] = p.idx;
       else
         overflow = true;
       ++n;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int kq = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
-      if (q < nk && p.lane == kq && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
+      if (q < nk && p.lane == kq[q] && (d2 < bd[q] || (d2 == bd[q] && p.idx < bi[q]))) {
         bd[q] = d2;
         bi[q] = p.idx;
       }
     }
   };
-  for (int n0 = 0; n0 < total; n0 += 4) {
-    smx_pt_rec rec[4];
-    int kk[4];
+  for (int n0 = 0; n0 < total; n0 += SMX_SEEDS_BATCH) {
+    smx_pt_rec rec[SMX_SEEDS_BATCH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      kk[u] = member(n0 + u < total ? n0 + u : 0);
-      rec[u] = m.lpg_pts[kk[u]];
-    }
+    for (int u = 0; u < SMX_SEEDS_BATCH; ++u) rec[u] = m.lpg_pts[member(n0 + u < total ? n0 + u : 0)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (n0 + u < total) take(rec[u], kk[u]);
+    for (int u = 0; u < SMX_SEEDS_BATCH; ++u)
+      if (n0 + u < total) take(rec[u]);
   }
   if (overflow || gi == 0x7fffffff) return false;
   d1sq = g2;
-  // ---- pass 2: the members of C, scored
+  // ---- pass 2: the members of C, scored (their lanepoint records: position, heading, lane)
   const double t_c = g2 + SMX_PI;
   const double r2 = within_radius * within_radius;
   ClosePick any, near;  // closest_lanepoints(pose) without a radius, and within `within_radius`
   any.none();
   near.none();
   int n_c = 0;
-  for (int i = 0; i < n; ++i) {
-    const smx_pt_rec p = m.lpg_pts[cand[i * stride]];
-    const double dx = p.x - px, dy = p.y - py;
-    const double d2 = dx * dx + dy * dy;
-    if (!(d2 <= t_c)) continue;
-    ++n_c;
-    const double rel = fabs(heading_relative_to(heading, m.lp_rec[p.idx].heading));
-    const double score = d2 + rel;
-    any.offer(score, d2, p.idx);
-    if (p.idx == gi || d2 <= r2) near.offer(score, d2, p.idx);
+  for (int i0 = 0; i0 < n; i0 += 4) {
+    double qx[4], qy[4], qh[4];
+    int qi[4], ql[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      qi[u] = cand[(i0 + u < n ? i0 + u : i0) * stride];
+      const smx_lp_rec* r = m.lp_rec + qi[u];
+      qx[u] = r->x;
+      qy[u] = r->y;
+      qh[u] = r->heading;
+      ql[u] = r->lane;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u < n) {
+        const double dx = qx[u] - px, dy = qy[u] - py;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 <= t_c) {
+          ++n_c;
+          const double rel = fabs(heading_relative_to(heading, qh[u]));
+          const double score = d2 + rel;
+          any.offer(score, d2, qi[u], ql[u]);
+          if (qi[u] == gi || d2 <= r2) near.offer(score, d2, qi[u], ql[u]);
+        }
+      }
+    }
   }
-  if (n_c > 10) return false;
+  if (n_c > 10 || any.idx < 0) return false;
   // ---- team_compute_path_seeds, an agent with a (possibly empty) route object and no fixed route
   s.f.none();
   s.road = -1;
   s.n_lanes = 0;
 #pragma unroll
   for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = -1;
-  {
-    const int lp = any.idx;
-    const int road = m.lane_road[m.lp_rec[lp].lane];
-    // _resolve_in_junction (sumo_road_network.py:842-860): the closest lanepoint lies on a junction road — the
-    // searches by road that follow are the team form's (few vehicles are inside a junction at any time)
-    if (m.road_is_junction[road]) return false;
-  }
-  s.road = near.idx >= 0 ? m.lane_road[m.lp_rec[near.idx].lane] : -1;
+  const int road_any = m.lane_road[any.lane], road_near = m.lane_road[near.lane];
+  // _resolve_in_junction (sumo_road_network.py:842-860): the closest lanepoint lies on a junction road — the
+  // searches by road that follow are the team form's (few vehicles are inside a junction at any time)
+  if (m.road_is_junction[road_any]) return false;
+  s.road = near.idx >= 0 ? road_near : -1;
   if (s.road >= 0) {
-    const int la = m.road_lane_off[s.road], lb = m.road_lane_off[s.road + 1];
-    s.n_lanes = lb - la;
-    const int nq = min(s.n_lanes, SMX_SEED_LANES);
-    bool guessed = s.road == c.prev_road && nq == nk && nk > 0;
+    // the start lanepoints were found on the way if this is last tick's road; a new road is the team form's
+    if (s.road != c.prev_road || nk == 0) return false;
+    s.n_lanes = c.prev_lanes;
 #pragma unroll
-    for (int q = 0; q < SMX_SEED_LANES; ++q) guessed = guessed && (q >= nk || bi[q] != 0x7fffffff);
-    if (guessed) {
-#pragma unroll
-      for (int q = 0; q < SMX_SEED_LANES; ++q) s.start[q] = q < nq ? bi[q] : -1;
-    } else {
-      const int q0 = m.road_lanes[la], q1 = nq > 1 ? m.road_lanes[la + 1] : -9, q2 = nq > 2 ? m.road_lanes[la + 2] : -9,
-                q3 = nq > 3 ? m.road_lanes[la + 3] : -9;
-      team_closest_filtered4<1>(m, px, py, q0, q1, q2, q3, nq, false, s.start, nullptr);
+    for (int q = 0; q < SMX_SEED_LANES; ++q) {
+      if (q < nk && bi[q] == 0x7fffffff) return false;
+      s.start[q] = q < nk ? bi[q] : -1;
     }
   }
   return true;

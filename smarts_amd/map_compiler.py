@@ -430,9 +430,9 @@ LP_REC = np.dtype(
 SHAPE_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("cum", "<f8"), ("len", "<f8")], align=False)
 SUCC_REC = np.dtype([("idx", "<i4"), ("lane", "<i4"), ("knot", "<i4"), ("hops", "<i4")], align=False)
 PT_REC = np.dtype([("x", "<f8"), ("y", "<f8"), ("idx", "<i4"), ("lane", "<i4")], align=False)
-SEG_REC = np.dtype([("x1", "<f8"), ("y1", "<f8"), ("x2", "<f8"), ("y2", "<f8"), ("thr", "<f8"), ("lane", "<i4"),
-                    ("v0", "<i4")], align=False)
-assert LP_REC.itemsize == 64 and SUCC_REC.itemsize == 16 and PT_REC.itemsize == 24 and SEG_REC.itemsize == 48
+SEG_REC = np.dtype([("x1", "<f8"), ("y1", "<f8"), ("x2", "<f8"), ("y2", "<f8"), ("thr", "<f8"), ("len", "<f8"), ("cum", "<f8"),
+                    ("lane", "<i4"), ("v0", "<i4")], align=False)
+assert LP_REC.itemsize == 64 and SUCC_REC.itemsize == 16 and PT_REC.itemsize == 24 and SEG_REC.itemsize == 64
 
 
 def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
@@ -514,6 +514,7 @@ def pack_tables(cm: CompiledMap) -> Dict[str, np.ndarray]:
                 d = math.sqrt(ex * ex + ey * ey)
                 shp["len"][v] = d
                 acc = acc + d
+    seg["len"], seg["cum"] = shp["len"][v0], shp["cum"][v0]  # (one cache line per segment: no vertex look-up behind it)
     return dict(lp_rec=rec, succ_rec=succ, lpg_pts=pts, sg_rec=seg, shape_rec=shp)
 
 

@@ -23,7 +23,7 @@ from .map_compiler import CompiledMap, compile_map, pack_tables
 from .sumo_map import load_net
 
 CACHE_NAME = "map.smxmap.npz"
-FORMAT = 4  # bump when CompiledMap / the packed records change
+FORMAT = 5  # bump when CompiledMap / the packed records change
 _SOURCES = ("map.net.xml", "map.smxnet.json.gz")
 
 
