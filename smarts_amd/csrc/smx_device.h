@@ -38,10 +38,12 @@ __device__ double smx_dbg_f[64];
 
 // Developer build (-DSMX_DEBUG_TIMING): per-phase wave-clock accumulation.
 #ifdef SMX_DEBUG_TIMING
-__device__ unsigned long long smx_prof[32];
+__device__ unsigned long long smx_prof[128];
 #define SMX_TSTAMP(var) unsigned long long var = wall_clock64()
+// (one workgroup in 64 reports: every wavefront adding to the same word serialises the chip's atomics and the
+//  stamps then measure themselves; slot + 64 counts the reports)
 #define SMX_TACC(slot, t0, t1) \
-  do { if ((threadIdx.x & 63) == 0) atomicAdd(&smx_prof[slot], (t1) - (t0)); } while (0)
+  do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&smx_prof[slot], (t1) - (t0)); atomicAdd(&smx_prof[(slot) + 64], 1ull); } } while (0)
 #else
 #define SMX_TSTAMP(var)
 #define SMX_TACC(slot, t0, t1)

@@ -983,7 +983,11 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, c
 // =================================================================================
 template <int SPACE>
 __global__ void __launch_bounds__(SMX_BLOCK) k_control_fast(const KernelArgs a) {
-  __shared__ double path_lds[3 * SMX_CTRL_WPS * SMX_BLOCK];
+  // the wanted path's waypoints, [element][lane]: 17 headings, then x and y of the first ten (lane_following_from_path
+  // reads no position beyond waypoint 9).  19 KB: eight workgroups per CU, every vehicle of 131 k resident at once — at
+  // 26 KB (all 51 elements) six fit, and the kernel ran a second round for a quarter of its workgroups.
+  constexpr int CTRL_XY = 10;
+  __shared__ double path_lds[(SMX_CTRL_WPS + 2 * CTRL_XY) * SMX_BLOCK];
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -1189,19 +1193,19 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_fast(const KernelArgs a) 
             double* col = path_lds + threadIdx.x;
             interpolate_knots_preloaded<KP>(m, r0, 0.0, 0.0, nk16, n16, D, px, py, SMX_CTRL_WPS, kx, ky, kh, kl, kw, ks_, fetch,
                                             [&](int i, const WaypointOut& w) {
-                                              double* q = col + (size_t)(i * 3) * SMX_BLOCK;
-                                              q[0] = w.x;
-                                              q[SMX_BLOCK] = w.y;
-                                              q[2 * SMX_BLOCK] = w.heading;
+                                              col[(size_t)i * SMX_BLOCK] = w.heading;
+                                              if (i < CTRL_XY) {
+                                                col[(size_t)(SMX_CTRL_WPS + i) * SMX_BLOCK] = w.x;
+                                                col[(size_t)(SMX_CTRL_WPS + CTRL_XY + i) * SMX_BLOCK] = w.y;
+                                              }
                                             });
             path.n = n16;
 #pragma unroll
             for (int k = 0; k < SMX_CTRL_WPS; ++k) {
-              const double* q = col + (size_t)(k * 3) * SMX_BLOCK;
               const bool held = k < n16;
-              path.x[k] = held ? q[0] : 0.0;
-              path.y[k] = held ? q[SMX_BLOCK] : 0.0;
-              path.h[k] = held ? q[2 * SMX_BLOCK] : 0.0;
+              path.h[k] = held ? col[(size_t)k * SMX_BLOCK] : 0.0;
+              path.x[k] = (held && k < CTRL_XY) ? col[(size_t)(SMX_CTRL_WPS + (k < CTRL_XY ? k : 0)) * SMX_BLOCK] : 0.0;
+              path.y[k] = (held && k < CTRL_XY) ? col[(size_t)(SMX_CTRL_WPS + CTRL_XY + (k < CTRL_XY ? k : 0)) * SMX_BLOCK] : 0.0;
             }
           }
         }
@@ -2500,26 +2504,29 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
 // hold its whole wavefront, and its registers would set this kernel's occupancy.
 // =================================================================================
 #define SMX_WPE_KNOTS 10  // knots after the start a path lane holds in registers
-#define SMX_WPE_POOL 384  // knot records per workgroup (64 paths; loop: 4.5 per path on average)
+#define SMX_WPE_POOL 320  // knot records per workgroup (64 paths; loop: 48 paths of 5.5 records on average, sigma 14; 288 overflowed often)
 struct __align__(8) WpKnot {
   double x, y, h, cum;  // position, unwrapped heading, arclength from the projected start
+};
+struct WpKnotLanes {
   short lane, strict;   // the knot's lane; lane of the last knot with an arclength strictly below this one's
-  int pad;
 };
 
 __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const int block) {
+  // 14.4 KB of LDS in all: eleven workgroups per CU (its registers allow twelve: three wavefronts per SIMD)
   __shared__ WpKnot pool[SMX_WPE_POOL];
+  __shared__ WpKnotLanes pool_lanes[SMX_WPE_POOL];
   __shared__ WpRowBook book;
   __shared__ double hdr_step[SMX_BLOCK], hdr_D[SMX_BLOCK];
   __shared__ unsigned short hdr_off[SMX_BLOCK];
   __shared__ unsigned char hdr_nrec[SMX_BLOCK], hdr_n[SMX_BLOCK];
   // lane width / speed limit / lane index of the path's start lane, and whether every knot held lies on that lane (almost
   // always): the waypoint lanes then need no table look-up behind their interval search
-  __shared__ double hdr_w0[SMX_BLOCK], hdr_s0[SMX_BLOCK];
+  __shared__ float hdr_w0[SMX_BLOCK], hdr_s0[SMX_BLOCK];  // (as they leave: the rows hold them as float32)
   __shared__ signed char hdr_li0[SMX_BLOCK];
   __shared__ unsigned char hdr_one_lane[SMX_BLOCK];
   __shared__ double first_wp[SMX_WPT_VEHICLES][3];
-  static_assert(sizeof(WpKnot) == 40, "WpKnot layout");
+  static_assert(sizeof(WpKnot) == 32 && sizeof(WpKnotLanes) == 4, "WpKnot layout");
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
@@ -2533,6 +2540,7 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   // words are loaded and dropped): the kernel runs two wavefronts per SIMD, and flags -> seeds -> knot list -> records
   // -> trip meter taken one after the other was five round trips of 2-4 us each under load (round 3: 85 of its 217 us).
   constexpr int KP = SMX_WPE_KNOTS;
+  SMX_TSTAMP(te0);
   const bool in_range = gid < total;
   const size_t g = in_range ? gid : 0, pth = g * SMX_WP_LANES + p0;
   int flags = a.st.flags[g];
@@ -2575,6 +2583,8 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   const bool listed = nk <= SMX_WPK_CAP;            // ... k_wp_walk's knot list holds all its knots
   const bool my_row = staged && prov < P;           // ... and one of the kept rows holds it
   // ---- 2. the path lane's walk over its knots: arclength, unwrapped headings, how many it needs
+  SMX_TSTAMP(te1);
+  SMX_TACC(32, te0, te1);
   bool tabled_path = false;
   int nrec = 0;
   double kx[KP], ky[KP], kh[KP], cum[KP];
@@ -2647,6 +2657,8 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     }
   }
   // ---- records handed out by an exclusive prefix sum over the wavefront's paths
+  SMX_TSTAMP(te2);
+  SMX_TACC(33, te1, te2);
   int incl = tabled_path ? nrec : 0;
   {
     const int lane = threadIdx.x & 63;
@@ -2701,8 +2713,8 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     hdr_off[col] = (unsigned short)off;
     hdr_nrec[col] = (unsigned char)nrec;
     hdr_n[col] = (unsigned char)n_first;
-    hdr_w0[col] = m.lane_width[lane0];
-    hdr_s0[col] = m.lane_speed[lane0];
+    hdr_w0[col] = (float)m.lane_width[lane0];
+    hdr_s0[col] = (float)m.lane_speed[lane0];
     hdr_li0[col] = (signed char)m.lane_index[lane0];
     {
       bool one = true;
@@ -2715,10 +2727,11 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     r.y = k0y;
     r.h = k0h;
     r.cum = 0.0;
-    r.lane = (short)lane0;
-    r.strict = (short)lane0;
-    r.pad = 0;
     pool[off] = r;
+    WpKnotLanes rl;
+    rl.lane = (short)lane0;
+    rl.strict = (short)lane0;
+    pool_lanes[off] = rl;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       if (k + 1 < nrec) {
@@ -2727,107 +2740,144 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
         q.y = ky[k];
         q.h = kh[k];
         q.cum = cum[k];
-        q.lane = (short)kl[k];
-        q.strict = (short)kstrict[k];
-        q.pad = 0;
         pool[off + k + 1] = q;
+        WpKnotLanes ql;
+        ql.lane = (short)kl[k];
+        ql.strict = (short)kstrict[k];
+        pool_lanes[off + k + 1] = ql;
       }
     }
   }
   __syncthreads();
-  // ---- 3. the waypoint slots of the workgroup's vehicles in memory order, a lane per waypoint
+  SMX_TSTAMP(te3);
+  SMX_TACC(34, te2, te3);
+  // ---- 3. the waypoint slots of the workgroup's vehicles in memory order, a lane per waypoint.  Four slots per lane
+  // and round, their arithmetic written without branches (every read at a clamped index, results selected at the end):
+  // the four dependency chains — header, interval search, two knot records, three divisions, the heading wrap — are
+  // independent, and straight-line code is what lets the compiler interleave them (a wavefront alone on its SIMD half
+  // the time issues one chain's instruction every ten cycles or so).  Only the rare lane look-ups keep their branch.
   {
     const int elems = SMX_WPT_VEHICLES * P * W;
-    int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per round
+    int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per slot
     int vv = row / P, slot = row - vv * P;                 // row = vv * P + slot: team vv's path row `slot`
     const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
-#pragma unroll 2
-    for (int e = threadIdx.x; e < (SMX_SKIP(a, 1 << 21) ? 0 : elems); e += SMX_BLOCK) {
-      const int src = book.src[row];
-      if (src != SMX_ROW_SKIP) {
-        double x = 0.0, y = 0.0;
-        float hd = 0.0f, wd = 0.0f, sp = 0.0f;
-        int ln = -1, li = 0;
-        if (src >= 0 && i < (int)book.count[row]) {
-          const int n = hdr_n[src], nr = hdr_nrec[src], koff = hdr_off[src];
-          const bool one_lane = hdr_one_lane[src] != 0;
-          const WpKnot* kn = pool + koff;
-          const double t = (i == n - 1) ? hdr_D[src] : (double)i * hdr_step[src];
-          // np.interp's interval: the last knot with cum <= t.  Cums do not decrease along the path, so that is the
-          // number of knots 1 .. nr-1 with cum <= t; the reads are issued together (a loop that stops at the first
-          // larger cum waits for one LDS round trip per knot)
-          int j = 0;
+    const int last_row = SMX_WPT_VEHICLES * P - 1;
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < (SMX_SKIP(a, 1 << 21) ? 0 : elems); e0 += U * SMX_BLOCK) {
+      int s_row[U], s_i[U], s_vv[U], s_slot[U];
+      bool s_in[U];
 #pragma unroll
-          for (int k = 1; k <= SMX_WPE_KNOTS; ++k) {
-            const double ck = pool[min(koff + k, SMX_WPE_POOL - 1)].cum;
-            j += (k < nr && ck <= t) ? 1 : 0;
-          }
-          const WpKnot K = kn[j];
-          double h = K.h;
-          x = K.x;
-          y = K.y;
-          double wj, sj;
-          if (one_lane) {
-            wj = hdr_w0[src];
-            sj = hdr_s0[src];
-          } else {
-            wj = m.lane_width[K.lane];
-            sj = m.lane_speed[K.lane];
-          }
-          if (j + 1 < nr) {
-            const WpKnot Q = kn[j + 1];
-            const double den = Q.cum - K.cum;
-            const double dt_ = t - K.cum;
-            const double sx = (Q.x - K.x) / den, sy = (Q.y - K.y) / den, sh = (Q.h - K.h) / den;
-            x = sx * dt_ + K.x;
-            y = sy * dt_ + K.y;
-            h = sh * dt_ + K.h;
-            if (Q.lane != K.lane) {
-              const double sw = (m.lane_width[Q.lane] - wj) / den, ss = (m.lane_speed[Q.lane] - sj) / den;
-              wj = sw * dt_ + wj;
-              sj = ss * dt_ + sj;
-            }
-          }
-          // (at or beyond the last knot: the knot itself; t == cum: the lane of the last knot strictly passed)
-          const int dl = (t == K.cum) ? (int)K.strict : (int)K.lane;
-          h = (n == 1) ? h : wrap_heading(h);
-          hd = (float)h;
-          wd = (float)wj;
-          sp = (float)sj;
-          ln = dl;
-          li = one_lane ? (int)hdr_li0[src] : m.lane_index[dl];
-          if (i == 0 && slot == 0) {  // first waypoint of the vehicle's first path: the trip meter's
-            first_wp[vv][0] = x;
-            first_wp[vv][1] = y;
-            first_wp[vv][2] = h;
-          }
+      for (int u = 0; u < U; ++u) {
+        s_in[u] = e0 + u * SMX_BLOCK < elems;
+        s_row[u] = min(row, last_row);
+        s_i[u] = i;
+        s_vv[u] = min(vv, SMX_WPT_VEHICLES - 1);
+        s_slot[u] = min(slot, P - 1);
+        row += drow;
+        slot += drow;
+        i += di;
+        if (i >= W) {
+          i -= W;
+          ++row;
+          ++slot;
         }
-        const size_t q = ((size_t)book.veh[vv] * P + slot) * W + i;
-        if (!SMX_SKIP(a, 1 << 20) || x == 1.2345e300) {  // (developer ablation: compute, do not store)
+        while (slot >= P) {
+          slot -= P;
+          ++vv;
+        }
+      }
+      SMX_TSTAMP(tr0);
+      double ox[U], oy[U], oh[U];
+      float ow[U], os[U];
+      int oln[U], oli[U], osrc[U], okl[U], oql[U];
+      bool owrite[U], ohave[U], oone[U], ointerior[U];
+      double oden[U], odt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = s_in[u] ? (int)book.src[s_row[u]] : (int)SMX_ROW_SKIP;
+        const bool have = src >= 0 && s_i[u] < (int)book.count[s_row[u]];
+        const int sc = have ? src : 0;
+        const int n = hdr_n[sc], nr = max((int)hdr_nrec[sc], 1), koff = hdr_off[sc];
+        const double t = (s_i[u] == n - 1) ? hdr_D[sc] : (double)s_i[u] * hdr_step[sc];
+        // np.interp's interval: the last knot with cum <= t.  Cums do not decrease along the path, so that is the
+        // number of knots 1 .. nr-1 with cum <= t (the reads are issued together)
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k <= SMX_WPE_KNOTS; ++k) {
+          const double ck = pool[min(koff + k, SMX_WPE_POOL - 1)].cum;
+          j += (k < nr && ck <= t) ? 1 : 0;
+        }
+        const bool interior = j + 1 < nr;
+        const int kj = min(koff + j, SMX_WPE_POOL - 1), qj = min(koff + (interior ? j + 1 : j), SMX_WPE_POOL - 1);
+        const WpKnot K = pool[kj];
+        const WpKnot Q = pool[qj];
+        const WpKnotLanes KL = pool_lanes[kj], QL = pool_lanes[qj];
+        const double den = interior ? Q.cum - K.cum : 1.0;
+        const double dt_ = t - K.cum;
+        const double sx = (Q.x - K.x) / den, sy = (Q.y - K.y) / den, sh = (Q.h - K.h) / den;
+        // (at or beyond the last knot: the knot itself; t == cum: the lane of the last knot strictly passed)
+        double h = interior ? sh * dt_ + K.h : K.h;
+        h = (n == 1) ? h : wrap_heading(h);
+        ox[u] = have ? (interior ? sx * dt_ + K.x : K.x) : 0.0;
+        oy[u] = have ? (interior ? sy * dt_ + K.y : K.y) : 0.0;
+        oh[u] = have ? h : 0.0;
+        ow[u] = have ? hdr_w0[sc] : 0.0f;
+        os[u] = have ? hdr_s0[sc] : 0.0f;
+        oln[u] = have ? ((t == K.cum) ? (int)KL.strict : (int)KL.lane) : -1;
+        oli[u] = have ? (int)hdr_li0[sc] : 0;
+        osrc[u] = src;
+        owrite[u] = src != SMX_ROW_SKIP;
+        ohave[u] = have;
+        oone[u] = hdr_one_lane[sc] != 0;
+        ointerior[u] = interior;
+        okl[u] = KL.lane;
+        oql[u] = QL.lane;
+        oden[u] = den;
+        odt[u] = dt_;
+      }
+      SMX_TSTAMP(tr1);
+      // a path whose knots do not all lie on its start lane (seldom): lane width / speed limit / index from the tables,
+      // interpolated where the interval joins two lanes
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ohave[u] && !oone[u]) {
+          double wj = m.lane_width[okl[u]], sj = m.lane_speed[okl[u]];
+          if (ointerior[u] && oql[u] != okl[u]) {
+            const double sw = (m.lane_width[oql[u]] - wj) / oden[u], ss = (m.lane_speed[oql[u]] - sj) / oden[u];
+            wj = sw * odt[u] + wj;
+            sj = ss * odt[u] + sj;
+          }
+          ow[u] = (float)wj;
+          os[u] = (float)sj;
+          oli[u] = m.lane_index[oln[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ohave[u] && s_i[u] == 0 && s_slot[u] == 0) {  // first waypoint of the vehicle's first path: the trip meter's
+          first_wp[s_vv[u]][0] = ox[u];
+          first_wp[s_vv[u]][1] = oy[u];
+          first_wp[s_vv[u]][2] = oh[u];
+        }
+        if (owrite[u] && (!SMX_SKIP(a, 1 << 20) || ox[u] == 1.2345e300)) {  // (developer ablation: compute, do not store)
+          const size_t q = ((size_t)book.veh[s_vv[u]] * P + s_slot[u]) * W + s_i[u];
           double* dst = o.wp_pos + q * 3;
-          dst[0] = x;
-          dst[1] = y;
+          dst[0] = ox[u];
+          dst[1] = oy[u];
           dst[2] = 0.0;
-          o.wp_heading[q] = hd;
-          o.wp_lane_width[q] = wd;
-          o.wp_speed_limit[q] = sp;
-          o.wp_lane_id[q] = (int16_t)ln;
-          o.wp_lane_index[q] = (int8_t)li;
+          o.wp_heading[q] = (float)oh[u];
+          o.wp_lane_width[q] = ow[u];
+          o.wp_speed_limit[q] = os[u];
+          o.wp_lane_id[q] = (int16_t)oln[u];
+          o.wp_lane_index[q] = (int8_t)oli[u];
         }
       }
-      row += drow;
-      slot += drow;
-      i += di;
-      if (i >= W) {
-        i -= W;
-        ++row;
-        ++slot;
-      }
-      while (slot >= P) {
-        slot -= P;
-        ++vv;
-      }
+      SMX_TSTAMP(tr2);
+      SMX_TACC(38, tr0, tr1);
+      SMX_TACC(39, tr1, tr2);
     }
+    SMX_TSTAMP(te4);
+    SMX_TACC(35, te3, te4);
     // wp_count: [vehicle][0] = number of paths, [1 + slot] = waypoints kept of the path in that row
     const int cells = SMX_WPT_VEHICLES * (P + 1);
     for (int e = threadIdx.x; e < cells; e += SMX_BLOCK) {
@@ -2837,6 +2887,7 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     }
   }
   __syncthreads();  // first_wp is complete
+  SMX_TSTAMP(te5);
   // ---- trip meter + reward (lane 0 of the team): path 0 is the lowest started lane's, row 0 of the vehicle
   if (live && !slow_team && p0 == 0) {
     // trip_meter_update on the words loaded at the top (no new vehicle comes here)
@@ -2873,6 +2924,9 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     }
     a.st.facts_i32[(size_t)SMX_FI_TRIP_HAS_WP * total + gid] = trip_has_wp ? 1 : 0;
   }
+  SMX_TSTAMP(te6);
+  SMX_TACC(36, te5, te6);
+  SMX_TACC(37, te0, te6);
 }
 
 // =================================================================================
@@ -4293,9 +4347,9 @@ extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; 
 
 #ifdef SMX_DEBUG_TIMING
 extern "C" int smx_prof_read(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 128 * sizeof(unsigned long long)) != hipSuccess) return -2;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[128] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(smx_prof), z, sizeof(z)) != hipSuccess) return -2;
   }
   return 0;

@@ -929,14 +929,14 @@ __device__ inline void lane_positions_at_offsets(const MapDev& m, int v0, int v1
   }
   // (the first hit: a later iteration of the descending loop overwrites a later hit with an earlier one)
   auto at = [&](int u, double off, double& ox, double& oy) {
-    smx_shape_rec a = r[0], b2 = r[1];
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-      if (u == q) {
-        a = r[q];
-        b2 = r[q + 1];
-      }
-    position_at_offset(a.x, a.y, b2.x, b2.y, a.len, off - a.cum, ox, oy);
+    // (selects, not an indexed copy of the records: that would live in scratch memory)
+    const double ax = u == 0 ? r[0].x : (u == 1 ? r[1].x : (u == 2 ? r[2].x : r[3].x));
+    const double ay = u == 0 ? r[0].y : (u == 1 ? r[1].y : (u == 2 ? r[2].y : r[3].y));
+    const double al = u == 0 ? r[0].len : (u == 1 ? r[1].len : (u == 2 ? r[2].len : r[3].len));
+    const double ac = u == 0 ? r[0].cum : (u == 1 ? r[1].cum : (u == 2 ? r[2].cum : r[3].cum));
+    const double bx = u == 0 ? r[1].x : (u == 1 ? r[2].x : (u == 2 ? r[3].x : r[4].x));
+    const double by = u == 0 ? r[1].y : (u == 1 ? r[2].y : (u == 2 ? r[3].y : r[4].y));
+    position_at_offset(ax, ay, bx, by, al, off - ac, ox, oy);
   };
   if (hs >= 0)
     at(hs, s_off, p1x, p1y);
@@ -955,6 +955,7 @@ __device__ inline void lane_positions_at_offsets(const MapDev& m, int v0, int v1
 __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, double pose_radius, int n_corners,
                                       const double* cx, const double* cy, const FactsCarry& c, double thr_max, int* cand,
                                       int stride, bool want_heading, RoadFacts& out, double& lane_heading) {
+  SMX_TSTAMP(tf0);
   const double radius = fmax(pose_radius, 2.0 * m.default_lane_width);
   if (!(c.valid && c.qx == c.qx && c.qy == c.qy && c.prev_dist < radius)) return false;
   const double dist_bound = (c.prev_dist + euclid(px, py, c.qx, c.qy)) * (1.0 + 1e-12) + 1e-9;
@@ -1022,6 +1023,8 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
     }
   }
   if (overflow) return false;
+  SMX_TSTAMP(tf1);
+  SMX_TACC(40, tf0, tf1);
   // ---- pass 2: the distances (distance_point_to_line, math.py:393-411), as team_road_facts takes them
   out.lane = -1;
   out.dist = SMX_INF;
@@ -1098,6 +1101,8 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
   }
   out.lane = lane_key == 0x7fffffff ? -1 : lane_key;
   lane_heading = 0.0;
+  SMX_TSTAMP(tf2);
+  SMX_TACC(41, tf1, tf2);
 #if defined(SMX_ABLATE)
   if ((SMX_ABLATE) & (1 << 25)) return true;
 #endif
@@ -1180,11 +1185,17 @@ __device__ inline bool facts_one_lane(const MapDev& m, double px, double py, dou
   s_off = fmax(s_off, 0.0);
   double p1x, p1y, p2x, p2y;
   const int vfrom = (v_near_cum <= s_off) ? v_near : v0;
+  SMX_TSTAMP(tf3);
+  SMX_TACC(42, tf2, tf3);
   lane_positions_at_offsets(m, v0, v1, vfrom, s_off, e_off, p1x, p1y, p2x, p2y);
+  SMX_TSTAMP(tf4);
+  SMX_TACC(43, tf3, tf4);
   const double ang = vec_to_radians(p2x - p1x, p2y - p1y);
   const double half = ang * 0.5;
   const double qz = sin(half), qw = cos(half);
   lane_heading = wrap_heading(atan2(2.0 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz));
+  SMX_TSTAMP(tf5);
+  SMX_TACC(44, tf4, tf5);
   return true;
 }
 

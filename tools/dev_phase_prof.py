@@ -15,7 +15,7 @@ cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto
 sim = BatchedSim(cm, cfg, spawn_episodes=2); lib = nat.load_library()
 sim.reset(); acts = torch.zeros((E, N), dtype=torch.int8, device='cuda')
 for _ in range(20): sim.step(acts)
-torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 32)(); lib.smx_prof_read(buf, 1)
+torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 128)(); lib.smx_prof_read(buf, 1)
 T = 50
 for _ in range(T): sim.step(acts)
 torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
