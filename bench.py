@@ -2,7 +2,8 @@
 """bench.py — the hot path's headline metric (BASELINE.json): aggregate env-steps/s.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or on its own:
+     without WORLD_SIZE in the environment it starts the N ranks itself, one child process per GPU, before touching a GPU)
 
 A "step" is one SMARTS tick of every environment instance of the shard: controllers, vehicle
 dynamics, collisions, sensors/observation build, events/reward/done and auto-reset — one
@@ -218,9 +219,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous (gloo, no GPU), all-reduce the ranks and print {n_gpus, rank_sum}: the CPU test of the launch path")
     args = ap.parse_args()
     if args.cpu_worker is not None:
         return cpu_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, before anything in this process
+        # has touched the GPU (torch is not even imported yet); rank 0 prints the line
+        from smarts_amd.sharding import self_launch
+
+        raise SystemExit(self_launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.launch_check:
+        os.environ.setdefault("SMX_DIST_BACKEND", "gloo")
+        import torch
+        import torch.distributed as dist
+
+        from smarts_amd import sharding
+
+        rank, _, world = sharding.init_process_group()
+        t = torch.tensor([float(rank)])
+        if world > 1:
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item())}))
+        return
 
     import torch
 
@@ -231,7 +255,7 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = sharding.init_process_group()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     dev_index = sharding.local_device_index(local_rank)
@@ -302,6 +326,12 @@ def main():
         region_s.append(el)
         alive_samples.append(float(sim.out["active"].sum().item()))
         done_ticks += args.steps
+    # alive agents of the whole job (every rank's shard)
+    alive_job = float(np.mean(alive_samples))
+    if world > 1:
+        t = torch.tensor([alive_job], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        alive_job = float(t.item())
     elapsed = float(np.median(region_s))
     kernel_ms = sim.read_step_ms()
 
@@ -375,8 +405,11 @@ def main():
                 "total_envs": total_envs,
                 "envs_per_gpu": E,
                 "vehicles_per_env": N,
-                "agent_steps_per_s": env_steps_per_s * N,
-                "alive_agents_per_tick": {"mean_rank0": alive_mean, "of": E * N,
+                # agent-steps of agents that HAVE a vehicle (rows written, controller run): slots whose agent is done
+                # until its env restarts are not counted (value x N would count them)
+                "alive_agent_steps_per_s": alive_job * args.steps / elapsed,
+                "alive_fraction": alive_job / (total_envs * N),
+                "alive_agents_per_tick": {"mean_rank0": alive_mean, "of": E * N, "mean_job": alive_job,
                                           "note": "an env restarts when all its agents are done; until then the "
                                                   "agents already done have no vehicle: rows and byte counts "
                                                   "are those of the alive agents"},

@@ -39,6 +39,38 @@ class ShardPlan:
         return seed + self.first_env + local_env
 
 
+def rank_environments(world: int, port: Optional[int] = None, base=None):
+    """The environment of every rank of a one-node job, as ``torch.distributed.run`` would set it (one process per
+    GPU): RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT (a free port when none is given)."""
+    import socket
+
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    base = dict(os.environ if base is None else base)
+    envs = []
+    for r in range(world):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        envs.append(e)
+    return envs
+
+
+def self_launch(argv, world: int, port: Optional[int] = None) -> int:
+    """Start ``world`` ranks of the command ``argv`` (one child process each, the reference's own data parallelism:
+    parallel_env.py:96-122) and wait for them; the caller has not touched the GPU (a process that has must not be
+    replaced or forked).  Rank 0 inherits stdout — its one JSON line is the job's; the other ranks' stdout is dropped.
+    Returns the largest exit code."""
+    import subprocess
+
+    procs = []
+    for r, env in enumerate(rank_environments(world, port)):
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return max((c if c >= 0 else 128 - c) for c in codes)
+
+
 def env_from_dist() -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from the torchrun environment (1 process if absent)."""
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

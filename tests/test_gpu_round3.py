@@ -1,0 +1,216 @@
+"""Round-3 GPU tests: what round 2 added, at the size it runs, and the reference's behavioural envelopes on the HIP path.
+
+* SMALL and LARGE launch forms bit for bit on more than 4 096 vehicles over a long auto-reset run, so that the alive
+  list spans several 1 024-thread workgroups and thins out (k_alive_list, the one-lane kernels and their slow
+  lists, k_waypoints_emit's pool);
+* BASELINE configs[3] and configs[4] at FULL size through size-independent properties and first / last slice
+  equality with a small-form batch;
+* the lane-following envelope of smarts/core/tests/test_controller_lane.py:99-147 and the +-2 px occupancy check of
+  smarts/core/tests/test_observations.py:132-152 (every OTHER vehicle's projected centre), both on the device outputs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OGM64 = dict(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)
+
+
+def _actions(rng, E, N):
+    return np.where(rng.random((E, N)) < 0.8, 0, rng.integers(1, 4, (E, N))).astype(np.int8)
+
+
+def _extra(extra):
+    from smarts_amd.lidar import Planar100
+
+    extra = dict(extra)
+    if extra.get("lidar") == "planar100":
+        extra["lidar"] = Planar100
+    return extra
+
+
+@pytest.mark.parametrize("name,E,N,ticks,extra", [
+    ("loop", 160, 32, 1200, OGM64),                        # 5 120 vehicles: five alive-list workgroups
+    ("minicity", 72, 64, 500, dict(lidar="planar100")),    # 4 608 vehicles, junction-rich map: long slow lists
+    ("4lane", 288, 16, 400, {}),                           # 4 608 vehicles, short episodes: restarts every few ticks
+])
+def test_strategies_agree_bit_for_bit_on_a_long_sparse_run(name, E, N, ticks, extra, compiled_maps):
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps(name)
+    spawns = make_spawns(cm, E, N, episodes=3, seed=77)
+    sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
+                                     launch_strategy=s, **_extra(extra)), spawns=spawns) for s in ("small", "large")]
+    rng = np.random.default_rng(77)
+    for s in sims:
+        s.reset()
+    alive_min, checks = 1.0, 0
+    for t in range(ticks):
+        acts = torch.from_numpy(_actions(rng, E, N)).cuda()
+        outs = [s.step(acts) for s in sims]
+        if t % 97 == 0 or t == ticks - 1:
+            torch.cuda.synchronize()
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), equal_nan=True), (t, k)
+            assert np.array_equal(sims[0].state.cpu().numpy(), sims[1].state.cpu().numpy(), equal_nan=True), t
+            assert np.array_equal(sims[0].flags.cpu().numpy(), sims[1].flags.cpu().numpy()), t
+            alive_min = min(alive_min, float(outs[0]["active"].float().mean().item()))
+            checks += 1
+    assert checks >= 5
+    assert alive_min < 0.7, alive_min  # the batch did thin out: compacted lists shorter than the launch
+    for s in sims:
+        s.close()
+
+
+@pytest.mark.parametrize("config,name,E,N,sub,ticks,extra", [
+    ("configs[3]", "loop", 4096, 32, 8, 12, OGM64),
+    ("configs[4]", "minicity", 4096, 64, 4, 8, dict(lidar="planar100")),
+])
+def test_baseline_configurations_at_full_size(config, name, E, N, sub, ticks, extra, compiled_maps):
+    """The whole batch of BASELINE configs[3] / configs[4]: `sub` distinct envs tiled E / sub times.  First and last
+    slice must equal a `sub`-env small-form batch bit for bit; rows obey the dense layout's invariants."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps(name)
+    spawns = make_spawns(cm, sub, N, episodes=1, seed=9)
+    big = np.tile(spawns, (1, E // sub, 1))
+    kw = dict(num_vehicles=N, neighbors=True, nb_radius=50.0, **_extra(extra))
+    sim = BatchedSim(cm, SimConfig(num_envs=E, **kw), spawns=big)
+    sim2 = BatchedSim(cm, SimConfig(num_envs=sub, launch_strategy="small", **kw), spawns=spawns)
+    assert not sim.small_form() and sim2.small_form()
+    rng = np.random.default_rng(9)
+    sim.reset(), sim2.reset()
+    for t in range(ticks):
+        a_small = _actions(rng, sub, N)
+        o1 = sim.step(torch.from_numpy(np.tile(a_small, (E // sub, 1))).cuda())
+        o2 = sim2.step(torch.from_numpy(a_small).cuda())
+    torch.cuda.synchronize()
+    for k in o2:
+        if k in ("ogm", "lidar_point", "wp_pos"):  # the big rows: first and last slice only (host memory)
+            a_first, a_last = (o1[k][:sub].cpu().numpy(), o1[k][E - sub:].cpu().numpy())
+        elif k == "learner":
+            a = o1[k].cpu().numpy()
+            a_first, a_last = a[:, :sub], a[:, E - sub:]
+        else:
+            a = o1[k].cpu().numpy()
+            a_first, a_last = a[:sub], a[E - sub:]
+        b = o2[k].cpu().numpy()
+        assert np.array_equal(a_first, b, equal_nan=True) and np.array_equal(a_last, b, equal_nan=True), (config, k)
+    act = o1["active"].cpu().numpy().astype(bool)
+    assert act.mean() > 0.5
+    wpc = o1["wp_count"].cpu().numpy()
+    assert (wpc[act][:, 0] >= 1).all() and (wpc[act][:, 1] == 20).all()
+    assert (np.abs(o1["wp_heading"].cpu().numpy()) <= np.pi + 1e-6).all()
+    lane = o1["ego_lane"].cpu().numpy()
+    assert (lane[act][:, 0] >= 0).all() and (lane[act][:, 0] < cm.n_lanes).all()
+    assert (o1["nb_count"].cpu().numpy() <= N - 1).all()
+    r = o1["reward"].cpu().numpy()
+    assert (np.abs(r) < 25).all() and 0.5 < np.median(r[act]) < 2.5
+    assert np.isfinite(o1["ego_pos"].cpu().numpy()).all()
+    if "ogm" in o1:
+        # every alive agent sees its own footprint at the centre of its grid (chunked: the grids are 537 MB)
+        for e0 in range(0, E, 512):
+            g = o1["ogm"][e0:e0 + 512, :, 31:33, 31:33].cpu().numpy().reshape(-1, 4)
+            a_ = act[e0:e0 + 512].reshape(-1)
+            assert (g[a_] == 255).all()
+    sim.close(), sim2.close()
+
+
+def test_lane_following_envelope_on_the_device(compiled_maps):
+    """smarts/core/tests/test_controller_lane.py:99-147 on the HIP path: Laner agents sending keep_lane on
+    scenarios/loop for 500 ticks — speed never falls back under 5 km/h once it exceeded it, mean speed > 5 m/s,
+    lateral error to the first waypoint of the current lane < 2.2 m at every tick and < 1 m on average.  64 agents,
+    one per env (no traffic, as in the reference's test), spread over the map's lanes."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    EGO_SPEED = 1  # include/smx.h SMX_EGO_SPEED
+    cm = compiled_maps("loop")
+    E, N = 64, 1
+    cfg = SimConfig(num_envs=E, num_vehicles=N, done_off_road=False, done_off_route=False, done_collision=False)
+    spawns = make_spawns(cm, E, N, episodes=1, seed=42)
+    sim = BatchedSim(cm, cfg, spawns=spawns)
+    out = sim.reset()
+    acts = torch.zeros((E, N), dtype=torch.int8, device="cuda")  # keep_lane
+    detected = np.zeros(E, bool)
+    speed_min = np.full(E, np.inf)
+    speed_sum, speed_n = np.zeros(E), np.zeros(E)
+    lat_max, lat_sum = np.zeros(E), np.zeros(E)
+    T = 500
+    for _ in range(T):
+        torch.cuda.synchronize()
+        pos = out["ego_pos"].cpu().numpy().reshape(E, 3)[:, :2]
+        speed = out["ego_f32"].cpu().numpy().reshape(E, -1)[:, EGO_SPEED].astype(np.float64)
+        wp = out["wp_pos"].cpu().numpy().reshape(E, cfg.wp_paths, cfg.wp_len, 3)[:, :, 0, :2]
+        wh = out["wp_heading"].cpu().numpy().reshape(E, cfg.wp_paths, cfg.wp_len)[:, :, 0].astype(np.float64)
+        cnt = out["wp_count"].cpu().numpy().reshape(E, cfg.wp_paths + 1)
+        assert (cnt[:, 0] >= 1).all()
+        d = np.linalg.norm(wp - pos[:, None, :], axis=2)
+        d[np.arange(cfg.wp_paths)[None, :] >= cnt[:, :1]] = np.inf
+        cur = d.argmin(axis=1)  # find_current_lane (lane_following_controller.py:367-374)
+        w0, h0 = wp[np.arange(E), cur], wh[np.arange(E), cur]
+        # Waypoint.signed_lateral_error: distance to the line through the waypoint along its heading (math.py:163-185)
+        hv = np.stack([np.cos(h0 + np.pi / 2), np.sin(h0 + np.pi / 2)], axis=1)
+        lat = np.abs((pos[:, 0] - w0[:, 0]) * hv[:, 1] - (pos[:, 1] - w0[:, 1]) * hv[:, 0])
+        detected |= speed > 5 / 3.6
+        speed_min = np.where(detected, np.minimum(speed_min, speed), speed_min)
+        speed_sum += np.where(detected, speed, 0.0)
+        speed_n += detected
+        lat_max = np.maximum(lat_max, lat)
+        lat_sum += lat
+        out = sim.step(acts)
+        assert not bool(out["done"].any().item())
+    assert detected.all()
+    assert (speed_min > 5 / 3.6).all(), speed_min.min()
+    assert (speed_sum / speed_n > 5).all()
+    assert (lat_max < 2.2).all(), lat_max.max()
+    assert (lat_sum / T < 1).all(), (lat_sum / T).max()
+    sim.close()
+
+
+def test_ogm_shows_every_other_vehicle_at_its_projected_centre(compiled_maps):
+    """smarts/core/tests/test_observations.py:132-152 (sample_vehicle_pos / apply_tolerance) on the device's grids:
+    wherever another vehicle's centre projects into an agent's view, the grid is non-zero within +-2 pixels."""
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    cm = compiled_maps("loop")
+    E, N, side, res = 16, 32, 64, 50 / 64
+    cfg = SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True, **OGM64)
+    sim = BatchedSim(cm, cfg, spawns=make_spawns(cm, E, N, episodes=2, seed=5))
+    out = sim.reset()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for t in range(30):
+        if t % 5 == 0:
+            torch.cuda.synchronize()
+            g = out["ogm"].cpu().numpy()
+            act = out["active"].cpu().numpy().astype(bool)
+            pos = sim.state[:2].cpu().numpy()                       # x, y  [2, E, N]
+            head = out["ego_f32"].cpu().numpy()[..., 0].astype(np.float64)  # ego heading
+            alive = (sim.flags.cpu().numpy() & 1).astype(bool)
+            for e in range(E):
+                for i in range(N):
+                    if not act[e, i]:
+                        continue
+                    h = head[e, i]
+                    rx, ry, fx, fy = np.cos(h), np.sin(h), -np.sin(h), np.cos(h)
+                    for j in range(N):
+                        if j == i or not alive[e, j]:
+                            continue
+                        dx, dy = pos[0, e, j] - pos[0, e, i], pos[1, e, j] - pos[1, e, i]
+                        cx, cy = dx * rx + dy * ry, dx * fx + dy * fy  # ego frame: x right, y ahead
+                        col, row = int(cx / res + side / 2), int(side / 2 - cy / res)
+                        if not (2 <= col < side - 2 and 2 <= row < side - 2):
+                            continue
+                        assert np.count_nonzero(g[e, i, row - 2:row + 2, col - 2:col + 2]), (t, e, i, j)
+                        checked += 1
+        out = sim.step(torch.from_numpy(_actions(rng, E, N)).cuda())
+    assert checked > 1000
+    sim.close()

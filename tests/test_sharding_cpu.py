@@ -87,3 +87,33 @@ def test_reward_done_gather_gloo_world2():
         for src in range(world):
             assert np.array_equal(got[src, 0], np.arange(12) + 100 * src)
             assert np.array_equal(got[src, 1], (np.arange(12) + src) % 2)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's one-GPU command)
+    must start two ranks itself — the reference's data parallelism is one process per env group
+    (smarts/env/wrappers/parallel_env.py:96-122) — and rank 0 must print the job's line.  --launch-check keeps the
+    children off the GPU: rendezvous over gloo, all-reduce of the ranks, {n_gpus, rank_sum}."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for n in (2, 3):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--launch-check"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout  # one line for the job, from rank 0
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == n and rec["rank_sum"] == n * (n - 1) / 2
+
+
+def test_rank_environments_are_torchrun_shaped():
+    from smarts_amd.sharding import rank_environments
+
+    envs = rank_environments(4, port=29999, base={})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29999" for e in envs)
