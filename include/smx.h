@@ -332,6 +332,7 @@ enum { /* indices into smx_outputs.count / .dtype: the pointers in declaration o
   SMX_OUT_LIDAR_POINT, SMX_OUT_DAGM, SMX_OUT_COLLIDEES,
   SMX_OUT_RW_LANE_COUNT, SMX_OUT_RW_LANE, SMX_OUT_RW_PATH_COUNT, SMX_OUT_RW_COUNT, SMX_OUT_RW_POS, SMX_OUT_RW_HEADING,
   SMX_OUT_RW_LANE_WIDTH, SMX_OUT_RW_SPEED_LIMIT, SMX_OUT_RW_LANE_INDEX, SMX_OUT_RW_LANE_ID,
+  SMX_OUT_FINAL_EGO_POS, SMX_OUT_FINAL_EGO_F32, SMX_OUT_FINAL_EGO_LANE, SMX_OUT_FINAL_EVENTS, SMX_OUT_FINAL_DIST,
   SMX_OUT_BUFFERS
 };
 typedef struct smx_outputs {
@@ -393,6 +394,16 @@ typedef struct smx_outputs {
   float* rw_speed_limit;
   int8_t* rw_lane_index;
   int16_t* rw_lane_id;
+  /* auto_reset only, all five or none (NULL): the low-dimensional rows of the FINISHING tick of an env that restarts
+   * inside the launch — the observation the reference hands back as info[agent]["env_obs"]
+   * (smarts/env/wrappers/parallel_env.py:303-309, smarts/env/hiway_env.py:243-246) — copied by k_commit before the
+   * reset pass overwrites ego_pos / ego_f32 / ego_lane / events / dist with the next episode's first observation.  Written
+   * only for the slots of an env whose env_done is raised this tick; same layouts as their namesakes. */
+  double* final_ego_pos;
+  float* final_ego_f32;
+  int16_t* final_ego_lane;
+  uint8_t* final_events;
+  double* final_dist;
   /* what the caller allocated: element count and SMX_DT_* of each buffer above, in declaration order
    * (SMX_OUT_*); 0 / SMX_DT_NONE for a NULL pointer */
   uint64_t count[SMX_OUT_BUFFERS];

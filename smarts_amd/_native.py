@@ -107,6 +107,7 @@ OUTPUT_FIELDS = [
     "ogm", "lidar_hit", "lidar_point", "dagm", "collidees",
     "rw_lane_count", "rw_lane", "rw_path_count", "rw_count", "rw_pos", "rw_heading", "rw_lane_width", "rw_speed_limit",
     "rw_lane_index", "rw_lane_id",
+    "final_ego_pos", "final_ego_f32", "final_ego_lane", "final_events", "final_dist",
 ]
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("learner"), "via_hit")
 OUTPUT_FIELDS.insert(OUTPUT_FIELDS.index("via_hit"), "via_near_count")

@@ -3516,6 +3516,16 @@ __device__ __forceinline__ void commit_role(const KernelArgs& a, const int block
   __syncthreads();
   const bool respawn = valid && env_respawn[valid ? env_local : 0] != 0;
   int next_episode = 0;
+  if (respawn && o.final_ego_pos != nullptr) {
+    // the finishing tick's rows, before the reset pass writes the next episode's first observation over them
+    // (parallel_env.py:303-309: what info[agent]["env_obs"] holds for the agents that ended with their env)
+    for (int k = 0; k < 3; ++k) o.final_ego_pos[gid * 3 + k] = o.ego_pos[gid * 3 + k];
+    for (int k = 0; k < SMX_EGO_F32_COUNT; ++k) o.final_ego_f32[gid * SMX_EGO_F32_COUNT + k] = o.ego_f32[gid * SMX_EGO_F32_COUNT + k];
+    o.final_ego_lane[gid * 2] = o.ego_lane[gid * 2];
+    o.final_ego_lane[gid * 2 + 1] = o.ego_lane[gid * 2 + 1];
+    for (int k = 0; k < SMX_EV_COUNT; ++k) o.final_events[gid * SMX_EV_COUNT + k] = o.events[gid * SMX_EV_COUNT + k];
+    o.final_dist[gid] = o.dist[gid];
+  }
   if (respawn) {
     next_episode = a.st.env_episode[env] + 1;
     respawn_vehicle(a, gid, total, next_episode);
@@ -4904,6 +4914,11 @@ static int check_buffers_impl(const smx_config& c, bool has_vias, bool need_lida
       OUT(rw_speed_limit, SMX_OUT_RW_SPEED_LIMIT, T * RWL * RWP * RWR, SMX_DT_F32, rw),
       OUT(rw_lane_index, SMX_OUT_RW_LANE_INDEX, T * RWL * RWP * RWR, SMX_DT_I8, rw),
       OUT(rw_lane_id, SMX_OUT_RW_LANE_ID, T * RWL * RWP * RWR, SMX_DT_I16, rw),
+      OUT(final_ego_pos, SMX_OUT_FINAL_EGO_POS, 3 * T, SMX_DT_F64, false),
+      OUT(final_ego_f32, SMX_OUT_FINAL_EGO_F32, SMX_EGO_F32_COUNT * T, SMX_DT_F32, false),
+      OUT(final_ego_lane, SMX_OUT_FINAL_EGO_LANE, 2 * T, SMX_DT_I16, false),
+      OUT(final_events, SMX_OUT_FINAL_EVENTS, SMX_EV_COUNT * T, SMX_DT_U8, false),
+      OUT(final_dist, SMX_OUT_FINAL_DIST, T, SMX_DT_F64, false),
   };
 #undef ST
 #undef OUT
@@ -4913,6 +4928,12 @@ static int check_buffers_impl(const smx_config& c, bool has_vias, bool need_lida
   }
   for (const BufSpec& b : specs)
     if (!check_spec(b, err)) return SMX_ERR_INVALID;
+  const int finals = (o->final_ego_pos != nullptr) + (o->final_ego_f32 != nullptr) + (o->final_ego_lane != nullptr) +
+                     (o->final_events != nullptr) + (o->final_dist != nullptr);
+  if (finals != 0 && finals != 5) {
+    err = "out.final_*: give all five buffers or none";
+    return SMX_ERR_INVALID;
+  }
   return SMX_OK;
 }
 

@@ -373,6 +373,13 @@ class BatchedSim:
         o["learner"] = self._learner[0]
         self.out = o
         o["collidees"] = z((E, N), torch.int64)  # bit j: touching the vehicle in slot j (read as unsigned)
+        if cfg.auto_reset:
+            # the finishing tick's low-dimensional rows of an env that restarts inside the launch (include/smx.h)
+            o["final_ego_pos"] = z((E, N, 3), torch.float64)
+            o["final_ego_f32"] = z((E, N, nat.EGO_F32_COUNT), torch.float32)
+            o["final_ego_lane"] = z((E, N, 2), torch.int16)
+            o["final_events"] = z((E, N, nat.EV_COUNT), torch.uint8)
+            o["final_dist"] = z((E, N), torch.float64)
         so = nat.SmxOutputs()
         for name in nat.OUTPUT_FIELDS:
             nat.bind_buffer(so, nat.OUTPUT_FIELDS, name, o.get(name))
@@ -388,7 +395,7 @@ class BatchedSim:
         """Bytes of observation/reward/done written per agent-step (dense layout)."""
         per = 0
         for name, t in self.out.items():
-            if name in ("env_done", "learner"):
+            if name in ("env_done", "learner") or name.startswith("final_"):
                 continue
             per += t[0, 0].numel() * t.element_size()
         return per
@@ -402,7 +409,8 @@ class BatchedSim:
         back, and every observation / reward / done byte of the dense rows.  NOT counted: the map tables
         (L2 / Infinity-Cache resident) and the hand-off buffers between the kernels of a tick (path seeds,
         road facts: ``handoff_bytes_per_agent_step``) — traffic this design adds, not traffic the path needs."""
-        o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items() if k not in ("env_done", "learner")}
+        o = {k: (t[0, 0].numel() * t.element_size()) for k, t in self.out.items()
+             if k not in ("env_done", "learner") and not k.startswith("final_")}  # (final_*: copied for restarting envs only)
         pose = 3 * 8 + 4  # x, y, heading + flags: what every sensor kernel reads of a vehicle
         ctrl_state = 14 * 8 + 4  # SMX_S_X .. SMX_S_MCL_Y + flags: read and written back by k_control
         obs_state_r, obs_state_w = 16 * 8 + 4 + 4, 12 * 8 + 4  # trip meter / accelerometer / driven-path fields, steps

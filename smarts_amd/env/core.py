@@ -132,7 +132,7 @@ class BatchCore:
     def __init__(self, scenario_dir: str, agent_specs: Dict[str, AgentSpec], num_envs: int, dt: float, seed: int,
                  auto_reset: bool, device: str = "cuda:0", waypoint_window: Optional[Tuple[int, int]] = (4, 20),
                  num_social: int = 0, vias: Optional[Dict[str, Sequence]] = None, social_model: str = "constant",
-                 missions: Optional[Dict[str, Any]] = None):
+                 missions: Optional[Dict[str, Any]] = None, spawns: str = "reference", shuffle_scenarios: bool = True):
         from ..engine import BatchedSim, make_spawns
         from ..scenario_build import load_compiled_map
 
@@ -152,7 +152,22 @@ class BatchCore:
                                              self.agent_ids)
         self.num_social = num_social
         self.cfg.social_model = social_model
+        # Start poses.  "reference": what hiway-v0 gives agents of a scenario without missions.pkl — a random endless
+        # mission each, from CPython's random stream (missions.reference_spawn_table); "synthetic": the benchmark's
+        # spawn table (PCG64(seed + env), 8 m apart on a lane, at the speed limit).  Scripted social
+        # vehicles (the stand-in for the scenario's SUMO flows) always start from the synthetic table.
+        if spawns not in ("reference", "synthetic"):
+            raise ValueError('spawns must be "reference" or "synthetic"')
+        spawn_mode = spawns
         spawns, where = make_spawns(self.cm, num_envs, self.N + num_social, episodes=4, seed=seed, return_lanes=True)
+        if spawn_mode == "reference":
+            from ..missions import reference_spawn_table
+            from ..sumo_map import load_net
+
+            ref = reference_spawn_table(load_net(self.scenario_dir), num_envs, self.N, seed, episodes=spawns.shape[0],
+                                        shuffle_scenarios=shuffle_scenarios)
+            slots = self.N + num_social
+            spawns.reshape(spawns.shape[0], num_envs, slots, 4)[:, :, :self.N] = ref.reshape(spawns.shape[0], num_envs, self.N, 4)
         # mission vias (sstudio Via per agent id) -> resolved lists per vehicle slot
         self.vias = None
         if vias:
@@ -282,6 +297,17 @@ class BatchCore:
         t = int(rows["env_ticks"][env])  # device clock: already that of the new episode after an auto-reset
         elapsed = round(t * self.dt, 6)
         return {self.agent_ids[i]: self.builder.build(er, i, t, elapsed) for i in range(self.N) if present[i]}
+
+    def final_observations(self, rows: Dict[str, np.ndarray], env: int, present: np.ndarray, step_count: int) -> Dict[str, Observation]:
+        """The finishing tick's observation of the agents of an env that restarted inside the launch
+        (``smx_outputs.final_*``: ego block, events, distance travelled — the low-dimensional part; the sensor rows of
+        that tick are gone): what the reference hands back as ``info[agent]["env_obs"]`` (parallel_env.py:303-309)."""
+        er = {k: v[env] for k, v in rows.items() if k not in self.PER_ENV_ROWS}
+        for k in ("ego_pos", "ego_f32", "ego_lane", "events", "dist"):
+            er[k] = rows["final_" + k][env]
+        elapsed = round(step_count * self.dt, 6)
+        return {self.agent_ids[i]: self.builder.build(er, i, step_count, elapsed, low_dimensional=True)
+                for i in range(self.N) if present[i]}
 
     def close(self):
         if not self._destroyed:

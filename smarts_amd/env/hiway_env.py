@@ -47,6 +47,7 @@ class HiWayEnv:
         social_model: str = "constant",
         vias: Optional[Dict[str, Sequence]] = None,
         missions: Optional[Union[Dict[str, Any], str]] = None,
+        spawns: str = "reference",
     ):
         self._log = logging.getLogger(self.__class__.__name__)
         if not headless or envision_record_data_replay_path or envision_endpoint:
@@ -83,6 +84,10 @@ class HiWayEnv:
 
             missions = load_missions(missions)
         self._missions = dict(missions) if missions else None
+        # where agents without a mission start: "reference" = a random endless mission each, as hiway-v0 draws them
+        # (missions.reference_spawn_table); "synthetic" = the benchmark's spawn table (engine.make_spawns)
+        self._spawns = spawns
+        self._shuffle_scenarios = bool(shuffle_scenarios)
         self._dones_registered = 0
         self._core: Optional[BatchCore] = None
         self._seed = seed
@@ -113,7 +118,8 @@ class HiWayEnv:
         """What must agree for envs to share one device batch (ParallelEnv)."""
         specs = self._agent_specs
         return (self._scenario, tuple(specs.keys()), tuple(repr(s.interface) for s in specs.values()), self._dt,
-                self._waypoint_window, self._num_social, self._social_model, repr(self._vias), repr(self._missions))
+                self._waypoint_window, self._num_social, self._social_model, repr(self._vias), repr(self._missions),
+                self._spawns, self._shuffle_scenarios)
 
     def seed(self, seed: int) -> int:
         """hiway_env.py:204-214.  Takes effect at the next ``reset`` that (re)builds the spawn table."""
@@ -133,7 +139,7 @@ class HiWayEnv:
             self._core = BatchCore(self._scenario, self._agent_specs, num_envs=1, dt=self._dt, seed=self._seed,
                                    auto_reset=False, device=self._device, waypoint_window=self._waypoint_window,
                                    num_social=self._num_social, vias=self._vias, social_model=self._social_model,
-                                   missions=self._missions)
+                                   missions=self._missions, spawns=self._spawns, shuffle_scenarios=self._shuffle_scenarios)
         return self._core
 
     def step(self, agent_actions) -> Tuple[Dict[str, Observation], Dict[str, float], Dict[str, bool], Dict[str, Any]]:

@@ -272,8 +272,21 @@ class ObservationBuilder:
             return None, None, None
         return self.lane_road_ids[lane], self.lane_ids[lane], int(lane_index)
 
-    def build(self, rows: Dict[str, np.ndarray], slot: int, step_count: int, elapsed_sim_time: float) -> Observation:
-        """``rows[k]`` is the [N, ...] slice of one env."""
+    def build(self, rows: Dict[str, np.ndarray], slot: int, step_count: int, elapsed_sim_time: float,
+              low_dimensional: bool = False) -> Observation:
+        """``rows[k]`` is the [N, ...] slice of one env.  ``low_dimensional``: the ego block and the events only (the
+        finishing tick of an env that restarted inside the launch: its sensor rows already hold the next episode)."""
+        if low_dimensional:
+            rows = dict(rows)
+            for k in ("wp_count", "nb_count", "rw_lane", "via_near_count", "collidees"):
+                if k in rows:
+                    rows[k] = np.zeros_like(rows[k]) if k != "rw_lane" else np.full_like(rows[k], -1)
+            saved = (self.ogm, self.dagm, self.lidar_rays)
+            self.ogm = self.dagm = self.lidar_rays = None
+            try:
+                return self.build(rows, slot, step_count, elapsed_sim_time)
+            finally:
+                self.ogm, self.dagm, self.lidar_rays = saved
         E = nat.EGO
         f = rows["ego_f32"][slot]
         v3 = lambda k: np.array(f[E[k]:E[k] + 3], dtype=np.float64)  # noqa: E731

@@ -56,14 +56,15 @@ class ParallelEnv:
         return self._proto.agent_specs
 
     def seed(self, seed: int) -> Sequence[int]:
-        """parallel_env.py:190-202: env i gets ``seed + i`` (the spawn generator of env i is
-        ``PCG64(seed + i)``)."""
+        """parallel_env.py:190-202: env i gets ``seed + i`` (its random stream: the missions of its agents,
+        missions.reference_spawn_table; with ``spawns="synthetic"`` the spawn generator ``PCG64(seed + i)``)."""
         if self._core is not None:
             self._core.close()
         p = self._proto
         self._core = BatchCore(p._scenario, p.agent_specs, num_envs=self._num_envs, dt=p._dt, seed=seed,
                                auto_reset=self._auto_reset, device=self._device, waypoint_window=p._waypoint_window or STD_WAYPOINT_WINDOW,
-                               num_social=p._num_social, vias=p._vias, social_model=p._social_model, missions=p._missions)
+                               num_social=p._num_social, vias=p._vias, social_model=p._social_model, missions=p._missions,
+                               spawns=p._spawns, shuffle_scenarios=p._shuffle_scenarios)
         self._seed = seed
         return [seed + i for i in range(self._num_envs)]
 
@@ -87,8 +88,9 @@ class ParallelEnv:
         core = self._core
         if len(actions) != self._num_envs:
             raise ValueError(f"expected {self._num_envs} action dicts, got {len(actions)}")
-        # the finishing tick's rows are overwritten by the in-launch auto-reset for envs that end;
-        # reward / done survive (keep_reward_done), the final observation itself is not kept
+        # the finishing tick's rows are overwritten by the in-launch auto-reset for envs that end; reward / done
+        # survive (keep_reward_done) and so do the low-dimensional rows of the final observation (smx_outputs.final_*)
+        ticks_before = core.step_count
         rows = core.host_rows(core.step_actions(actions))
         obs_b, rew_b, done_b, info_b = [], [], [], []
         for e in range(self._num_envs):
@@ -99,7 +101,16 @@ class ParallelEnv:
                 observations = {aid: core.agent_specs[aid].observation_adapter(o) for aid, o in first_obs.items()}
                 rewards = {aid: float(rows["reward"][e, i]) for i, aid in enumerate(core.agent_ids) if done_row[i]}
                 dones = {aid: True for i, aid in enumerate(core.agent_ids) if done_row[i]}
-                infos = {aid: {"score": None, "env_obs": None} for aid in dones}
+                # info["env_obs"]: the finishing tick's observation (parallel_env.py:303-309, hiway_env.py:243-246), its
+                # ego block and events; info["score"]: the distance travelled as of that tick (agent_manager.py:233-234)
+                last = core.final_observations(rows, e, done_row, int(ticks_before[e]) + 1)
+                infos = {}
+                for i, aid in enumerate(core.agent_ids):
+                    if done_row[i]:
+                        spec = core.agent_specs[aid]
+                        info = {"score": float(rows["final_dist"][e, i]), "env_obs": last[aid]}
+                        infos[aid] = spec.info_adapter(last[aid], float(rows["reward"][e, i]), info)
+                        rewards[aid] = spec.reward_adapter(last[aid], rewards[aid])
                 self._dones_registered[e] = 0
                 dones["__all__"] = True
             else:

@@ -179,6 +179,137 @@ def plan_mission(net: SumoNet, mission: Mission) -> PlannedMission:
     return PlannedMission(start_pos, start_heading, (goal_pos[0], goal_pos[1], 2.0), tuple(roads))
 
 
+def _polygon_offset_with_minimum_distance(point: Sequence[float], shape: np.ndarray) -> float:
+    """sumolib.geomhelper.polygonOffsetWithMinimumDistanceToPoint(point, shape, perpendicular=False), whose in-tree
+    twin is utils/math.py:370-390 (with line_offset_with_minimum_distance_to_point :348-367)."""
+    px, py = float(point[0]), float(point[1])
+    min_dist, min_offset, seen = 1e400, -1.0, 0.0
+    for (x1, y1), (x2, y2) in zip(shape[:-1], shape[1:]):
+        x1, y1, x2, y2 = float(x1), float(y1), float(x2), float(y2)
+        ex, ey = x1 - x2, y1 - y2
+        d = math.sqrt(ex * ex + ey * ey)
+        u = ((px - x1) * (x2 - x1)) + ((py - y1) * (y2 - y1))
+        if d == 0.0 or u < 0.0 or u > d * d:
+            pos = 0.0 if u < 0.0 else d
+        else:
+            pos = u / d
+        # position_at_offset (utils/math.py:300-316) on the segment, then the distance to it
+        def close(a, b):
+            return abs(a - b) <= max(1e-09 * max(abs(a), abs(b)), 0.0)
+        if close(pos, 0.0):
+            fx, fy = x1, y1
+        elif close(d, pos):
+            fx, fy = x2, y2
+        else:
+            fx, fy = x1 + (x2 - x1) * (pos / d), y1 + (y2 - y1) * (pos / d)
+        gx, gy = px - fx, py - fy
+        dist = math.sqrt(gx * gx + gy * gy)
+        if dist < min_dist:
+            min_dist, min_offset = dist, pos + seen
+        seen += d
+    return min_offset
+
+
+def _offset_along_lane(shape: np.ndarray, point: Sequence[float]) -> float:
+    """sumo_road_network.py:477-491."""
+    px, py = float(point[0]), float(point[1])
+    if not any(float(x) == px and float(y) == py for x, y in shape):
+        return _polygon_offset_with_minimum_distance(point, shape)
+    offset = 0.0
+    for i in range(len(shape) - 1):
+        if float(shape[i][0]) == px and float(shape[i][1]) == py:
+            break
+        ex, ey = float(shape[i][0] - shape[i + 1][0]), float(shape[i][1] - shape[i + 1][1])
+        offset += math.sqrt(ex * ex + ey * ey)
+    return offset
+
+
+def _center_pose_at_point(lane, point: Sequence[float]):
+    """Lane.center_pose_at_point (road_map.py:390-396): position on the centre line closest to `point` and the lane's
+    heading there, through the quaternion as the reference's Pose holds it (coordinates.py:394-403,
+    utils/math.py:78-94)."""
+    shape = np.asarray(lane.getShape(False), dtype=np.float64)
+    length = lane.getLength()
+    off = _offset_along_lane(shape, point)
+    x, y = _position_at_shape_offset(shape, off)
+    s_off, e_off = (length - 1, length) if off >= length else (off, off + 1)
+    s_off = max(s_off, 0)
+    x1, y1 = _position_at_shape_offset(shape, s_off)
+    x2, y2 = _position_at_shape_offset(shape, e_off)
+    # vec_to_radians without Heading()'s wrap, then fast_quaternion_from_angle, then yaw_from_quaternion + Heading
+    vx, vy = x2 - x1, y2 - y1
+    r = math.atan2(abs(vy), abs(vx))
+    if vx < 0:
+        ang = (r + 0.5 * math.pi) % (2 * math.pi) if vy < 0 else (0.5 * math.pi - r) % (2 * math.pi)
+    elif vy < 0:
+        ang = (1.5 * math.pi - r) % (2 * math.pi)
+    else:
+        ang = (r - 0.5 * math.pi) % (2 * math.pi)
+    half = ang * 0.5
+    qz, qw = math.sin(half), math.cos(half)
+    yaw = math.atan2(2 * (0.0 * 0.0 + qw * qz), qw * qw + 0.0 * 0.0 - 0.0 * 0.0 - qz * qz)
+    heading = yaw % (2 * math.pi)
+    if heading > math.pi:
+        heading -= 2 * math.pi
+    return (x, y), heading
+
+
+def reference_spawn_table(net: SumoNet, num_envs: int, count: int, seed: int, episodes: int = 4,
+                          shuffle_scenarios: bool = True) -> np.ndarray:
+    """Spawn poses ``[episodes, num_envs * count, 4]`` (x, y, heading, speed 0) of agents without missions, as
+    ``hiway-v0`` starts them: env ``e`` of a ParallelEnv is seeded ``seed + e`` (parallel_env.py:190-202); every
+    ``reset`` draws the scenario rolls again (scenario.py:211-214), then one ``Mission.random_endless_mission`` per
+    agent; the agents' vehicles, created after all missions are drawn, take a ``gen_id()`` each
+    (vehicle_index.py:602: ``random.getrandbits(128)``) from the same stream.  The vehicle's centre lies half a
+    chassis length behind the mission's start (Pose.from_front_bumper, vehicle.py:379-387); it stands still
+    (TrapEntryTactic.default_entry_speed is None).  Episode 0 is pinned by tests/golden/default_missions.npz (the
+    reference's own draw); the stream positions of later episodes follow from the calls named here (read, not run:
+    hiway-v0 cannot run in this tree)."""
+    import random as _random
+
+    out = np.zeros((episodes, num_envs * count, 4), dtype=np.float64)
+    for e in range(num_envs):
+        rng = _random.Random(seed + e)
+        for ep in range(episodes):
+            ms = _draw_endless_missions(net, count, rng, 3 if shuffle_scenarios else 0)
+            for i, m in enumerate(ms):
+                x, y, h = m.spawn_pose()
+                out[ep, e * count + i] = (x, y, h, 0.0)
+            for _ in range(count):
+                rng.getrandbits(128)
+    return out
+
+
+def random_endless_missions(net: SumoNet, count: int, seed: int, scenario_rolls: int = 3) -> List[PlannedMission]:
+    """What ``hiway-v0`` gives agents of a scenario without ``missions.pkl``: ``Mission.random_endless_mission``
+    (plan.py:225-249) over ``SumoRoadNetwork.random_route(1)`` (sumo_road_network.py:803-810), one per agent in
+    ``agent_specs`` order (``TrapManager.init_traps``, trap_manager.py:83-92), drawn from CPython's ``random`` stream as
+    ``smarts.core.seed(seed)`` leaves it (core/__init__.py:39-44).  Between the seeding and the first mission
+    ``Scenario.scenario_variations`` draws three ``random.randint`` rolls for the one scenario root when scenarios
+    are shuffled (scenario.py:211-214; ``HiWayEnv(shuffle_scenarios=True)`` is the default): ``scenario_rolls``.
+    Returned as planned missions with an empty route (endless) and no goal."""
+    import random as _random
+
+    return _draw_endless_missions(net, count, _random.Random(seed), scenario_rolls)
+
+
+def _draw_endless_missions(net: SumoNet, count: int, rng, scenario_rolls: int) -> List[PlannedMission]:
+    for _ in range(scenario_rolls):
+        rng.randint(0, 1)  # routes / agent missions / social agents: one candidate each in an unbuilt scenario
+    out = []
+    edges = net.getEdges(False)
+    for _ in range(count):
+        edge = rng.choice(edges)                # random_route(1).roads[0]
+        lane = rng.choice(edge.getLanes())      # random.choice(road.lanes)
+        offset = rng.random() * 0.3 + (0.9 - 0.3)
+        offset *= lane.getLength()
+        shape = np.asarray(lane.getShape(False), dtype=np.float64)
+        coord = _position_at_shape_offset(shape, offset)  # n_lane.from_lane_coord(RefLinePoint(offset))
+        pos, heading = _center_pose_at_point(lane, coord)
+        out.append(PlannedMission((float(pos[0]), float(pos[1])), float(heading), (0.0, 0.0, 0.0), ()))
+    return out
+
+
 def load_missions(source: Union[str, dict]) -> Dict[str, Mission]:
     """Missions of a scenario as JSON (the ``missions.pkl`` of the reference's ``scenario build`` holds pickled
     sstudio objects): ``{agent id: {"begin": [road, lane index, offset], "end": [...], "via": [road, ...]}}``."""

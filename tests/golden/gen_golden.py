@@ -914,6 +914,31 @@ def dump_road_waypoints(rn, net, rng, name):
     return out
 
 
+def dump_default_missions(nets):
+    """What hiway-v0 assigns agents of a scenario without missions.pkl: the reference's own
+    Mission.random_endless_mission (plan.py:225-249) over SumoRoadNetwork.random_route (sumo_road_network.py:803-810),
+    four in a row from CPython's `random` stream after smarts.core.seed(42) — straight after the seeding (`rolls0`) and
+    after the three random.randint rolls Scenario.scenario_variations draws for one shuffled scenario root
+    (scenario.py:211-214; `rolls3`: the stream position at which hiway-v0's TrapManager asks)."""
+    import random
+
+    import smarts.core
+    from smarts.core.plan import Mission
+
+    out = {}
+    for name, net in nets.items():
+        rn = make_reference_road_network(net)
+        for rolls in (0, 3):
+            smarts.core.seed(42)
+            for _ in range(rolls):
+                random.randint(0, 1)
+            ms = [Mission.random_endless_mission(rn) for _ in range(4)]
+            out[f"{name}_rolls{rolls}_position"] = np.array([np.asarray(m.start.position, dtype=np.float64)[:2] for m in ms])
+            out[f"{name}_rolls{rolls}_heading"] = np.array([float(m.start.heading) for m in ms])
+            assert all(m.goal.is_endless() for m in ms)
+    return out
+
+
 def main():
     install_reference()
     from smarts_amd.sumo_map import load_net
@@ -944,6 +969,10 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"missions_{name}.npz"), **ms)
             print(name, "missions: routes", int(ms["n_routes"]), "poses", len(ms["poses"]), "off-route",
                   int(ms["off_route"].sum()), "wrong-way", int(ms["wrong_way"].sum()))
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "default_missions"):
+        nets = {n: load_net(os.path.join(REF, rel)) for n, rel in SCENARIOS.items()}
+        np.savez_compressed(os.path.join(OUT, "default_missions.npz"), **dump_default_missions(nets))
+        print("default missions written")
     if os.environ.get("GOLDEN_ONLY", "") in ("", "roadwp"):
         for name, rel in SCENARIOS.items():
             net = load_net(os.path.join(REF, rel))
@@ -951,7 +980,7 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"road_waypoints_{name}.npz"), **rw)
             print(name, "road waypoints: poses", len(rw["poses"]), "lanes", len(rw["lane"]), "paths", len(rw["wp_off"]) - 1,
                   "raised", int(rw["raised"].sum()))
-    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias", "missions", "roadwp"):
+    if os.environ.get("GOLDEN_ONLY", "") in ("lidar", "stdobs", "sensors", "trajectory", "vias", "missions", "roadwp", "default_missions"):
         return
     for name, rel in SCENARIOS.items():
         net = load_net(os.path.join(REF, rel))

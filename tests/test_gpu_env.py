@@ -77,7 +77,13 @@ def test_hiway_env_matches_the_oracle_on_config0(nets, compiled_maps):
     env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs=specs, seed=42)
     cm = compiled_maps("loop")
     cfg = sim_config_from_interface(itf, 1, 4, 0.1, False)
-    ob = parity.OracleBatch(nets("loop"), cm, cfg, make_spawns(cm, 1, 4, episodes=4, seed=42)[0])
+    # without missions every agent starts where the reference's Mission.random_endless_mission puts it under seed 42
+    # (tests/golden/default_missions.npz, the reference's own draw; test_default_spawns_are_the_references below)
+    from smarts_amd.missions import reference_spawn_table
+
+    spawn = reference_spawn_table(nets("loop"), 1, 4, 42, episodes=4)
+    assert not np.allclose(spawn[0], make_spawns(cm, 1, 4, episodes=4, seed=42)[0])
+    ob = parity.OracleBatch(nets("loop"), cm, cfg, spawn[0])
     obs = env.reset()
     ref = ob.envs[0].reset_observe()
     script = ["keep_lane", "change_lane_left", "slow_down", "keep_lane", "change_lane_right", "keep_lane"]
@@ -357,3 +363,67 @@ def test_lane_action_code_that_names_no_action_is_reported_at_sync(compiled_maps
             sim.step(torch.zeros((2, 3), dtype=torch.int8, device="cuda"))
         assert sim._learner_k == k
         sim.close()
+
+
+def test_default_spawns_are_the_references(nets):
+    """BASELINE configs[0] ("parity seed"): hiway-v0 on scenarios/loop without missions.pkl starts its four agents on
+    Mission.random_endless_mission x 4 drawn after smarts.core.seed(42) and the scenario rolls (plan.py:225-249,
+    sumo_road_network.py:803-810, scenario.py:211-214); the fixture holds the reference's own draw.  The first reset of
+    the env must put the vehicles half a chassis length behind those starts (Pose.from_front_bumper), standing."""
+    import math
+    import os
+
+    from smarts_amd.env import Agent, AgentInterface, AgentSpec, AgentType, HiWayEnv
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "default_missions.npz"))
+    ids = [f"agent_{i}" for i in range(4)]
+    itf = AgentInterface.from_type(AgentType.Laner)
+    specs = {a: AgentSpec(interface=itf, agent_builder=lambda: Agent.from_function(lambda _: "keep_lane")) for a in ids}
+    env = HiWayEnv(scenarios=["scenarios/loop"], agent_specs=specs, seed=42)
+    obs = env.reset()
+    for i, a in enumerate(ids):
+        start, heading = g["loop_rolls3_position"][i], float(g["loop_rolls3_heading"][i])
+        e = obs[a].ego_vehicle_state
+        ang = (heading + math.pi * 0.5) % (2 * math.pi)
+        centre = (start[0] - math.cos(ang) * 0.5 * 3.68, start[1] - math.sin(ang) * 0.5 * 3.68)
+        assert np.allclose(e.position[:2], centre, atol=1e-9), (a, e.position, centre)
+        assert abs(float(e.heading) - heading) < 1e-6 and abs(float(e.speed)) < 1e-9
+    env.close()
+
+
+def test_parallel_env_auto_reset_keeps_the_final_observation():
+    """smarts/env/wrappers/parallel_env.py:303-309 + smarts/env/hiway_env.py:243-246: under auto_reset the
+    observation returned with dones["__all__"] is the next episode's first one, and the finishing tick's observation
+    travels in info[agent]["env_obs"] (its score in info["score"]).  The device keeps that tick's low-dimensional rows
+    (smx_outputs.final_*): they must equal what the same envs report without auto_reset."""
+    from smarts_amd.env import ParallelEnv
+
+    acts = [{"Agent_0": "keep_lane", "Agent_1": "change_lane_left"}] * 3
+    finals = {}
+    for auto_reset in (True, False):
+        env = ParallelEnv(env_constructors=[_ctor(3)] * 3, auto_reset=auto_reset, seed=7)
+        try:
+            first = env.reset()
+            env.step(acts)
+            obs, rewards, dones, infos = env.step(acts)
+            assert all(d["__all__"] for d in dones)
+            finals[auto_reset] = (obs, rewards, infos)
+            if auto_reset:
+                # the observations are those of the new episode (episode 1 of the spawn table): standing vehicles
+                for e in range(3):
+                    for a in ("Agent_0", "Agent_1"):
+                        assert obs[e][a].ego_vehicle_state.speed == pytest.approx(0.0, abs=1e-9)
+                        assert not np.allclose(obs[e][a].ego_vehicle_state.position, first[e][a].ego_vehicle_state.position)
+        finally:
+            env.close()
+    (_, rew_a, info_a), (obs_b, rew_b, info_b) = finals[True], finals[False]
+    for e in range(3):
+        for a in ("Agent_0", "Agent_1"):
+            last, ref = info_a[e][a]["env_obs"], obs_b[e][a]
+            assert last is not None and last.events.reached_max_episode_steps
+            assert np.array_equal(last.ego_vehicle_state.position, ref.ego_vehicle_state.position)
+            assert float(last.ego_vehicle_state.heading) == float(ref.ego_vehicle_state.heading)
+            assert last.ego_vehicle_state.speed == ref.ego_vehicle_state.speed
+            assert last.ego_vehicle_state.lane_id == ref.ego_vehicle_state.lane_id
+            assert last.events == ref.events
+            assert info_a[e][a]["score"] == info_b[e][a]["score"] and rew_a[e][a] == rew_b[e][a]
