@@ -464,9 +464,14 @@ def test_done_agents_leave_and_auto_reset(name, E, N, nets, compiled_maps):
     ref = _host(twin.reset())
     got = _host(out)
     for k in ref:
-        if k in ("reward", "done", "learner"):
-            continue  # the auto-reset tick keeps the finishing tick's reward / done
+        if k in ("reward", "done", "learner") or k.startswith("final_"):
+            continue  # the auto-reset tick keeps the finishing tick's reward / done (and its final rows)
         assert np.array_equal(ref[k], got[k], equal_nan=True), k
+    # the finishing tick's low-dimensional rows survived in final_* (smx_outputs): every agent ended on the step limit
+    fin = got["final_events"]
+    assert (fin[..., nat.EV_REACHED_MAX_EPISODE_STEPS] == 1).all()
+    assert (got["final_dist"] > 0).all() and np.isfinite(got["final_ego_pos"]).all()
+    assert not np.allclose(got["final_ego_pos"][:, :2], pos)
     twin.close()
     sim.close()
 

@@ -103,7 +103,9 @@ def test_baseline_configurations_at_full_size(config, name, E, N, sub, ticks, ex
     act = o1["active"].cpu().numpy().astype(bool)
     assert act.mean() > 0.5
     wpc = o1["wp_count"].cpu().numpy()
-    assert (wpc[act][:, 0] >= 1).all() and (wpc[act][:, 1] == 20).all()
+    assert (wpc[act][:, 0] >= 1).all() and (wpc[act][:, 1] >= 1).all() and (wpc[act][:, 1] <= 20).all()
+    if name == "loop":  # a closed circuit: every path runs the whole lookahead (minicity has dead ends)
+        assert (wpc[act][:, 1] == 20).all()
     assert (np.abs(o1["wp_heading"].cpu().numpy()) <= np.pi + 1e-6).all()
     lane = o1["ego_lane"].cpu().numpy()
     assert (lane[act][:, 0] >= 0).all() and (lane[act][:, 0] < cm.n_lanes).all()
