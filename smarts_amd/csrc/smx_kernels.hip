@@ -2097,22 +2097,21 @@ __global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs
 // k_wp_walk: the chain walks of the waypoints sensor, one lane per (vehicle, seed lane) and nothing else —
 // no LDS, few registers, so that many wavefronts per SIMD hide the dependent loads.  Leaves the knot list of
 // the seed lane's first path and the number of paths that start there (KnotLists).
-__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
+// (`honour_pending`: pass over a vehicle whose seeds the slow chain is still looking for — k_scan_fast; the slow chain's
+// own walk and the walk of the reset pass's new vehicles take every vehicle they are given)
+__device__ __forceinline__ void wp_walk_for(const KernelArgs& a, const size_t gid, const int p0, const bool honour_pending) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const size_t paths = total * SMX_WP_LANES;
-  const size_t lane_no = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
-  const size_t gid = launch_vehicle(a, lane_no / SMX_WP_LANES, total);
   if (gid >= total) return;
-  const int p0 = (int)(lane_no % SMX_WP_LANES);
   const size_t path = gid * SMX_WP_LANES + p0;
   const int flags = a.st.flags[gid];
   int n = 0, nk = 0, cnt = 0;
   double D = 0.0;
-  // (a vehicle whose seeds the slow chain is still looking for has no list this tick: k_scan_fast)
-  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST)) &&
-      !(a.seed_pending != nullptr && a.seed_pending[gid])) {
+  // (nothing of a pending vehicle's lists is touched here: the slow chain writes them meanwhile, on another stream)
+  if (honour_pending && a.seed_pending != nullptr && a.seed_pending[gid]) return;
+  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST))) {
     const PathSeeds seed = load_seeds(a, gid, total);
     if (seed.road >= 0 && seed.n_lanes <= SMX_WP_LANES && p0 < seed.n_lanes) {
       const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
@@ -2172,6 +2171,43 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
   a.knots.cnt[path] = (uint8_t)cnt;
   a.knots.D[path] = D;
   if (n == 0) a.knots.key[path] = -1;  // nothing here for the next tick's controller to reuse
+}
+
+__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
+  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  const size_t lane_no = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
+  wp_walk_for(a, launch_vehicle(a, lane_no / SMX_WP_LANES, total), (int)(lane_no % SMX_WP_LANES), true);
+}
+
+// the slow chain's vehicles (their seeds come from k_scan_listed): a fixed grid striding the slow list.  Their rows
+// leave through k_waypoints_listed; the lists are for the next tick's k_control_fast.
+__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk_listed(const KernelArgs a) {
+  const int count = *a.slow_count;
+  constexpr int VPB = SMX_BLOCK / SMX_WP_LANES;
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
+    wp_walk_for(a, (size_t)a.slow_list[i], (int)threadIdx.x % SMX_WP_LANES, false);
+}
+
+// the vehicles the reset pass has just created (k_first: steps == 1, SMX_F_FIRST already cleared): their knot lists,
+// so that the next tick's k_control_fast serves them too (a new vehicle without lists went through the slow
+// controller, two launches of pure latency in front of everything else of the tick).  A workgroup looks at the
+// words of 64 vehicles with one load and a ballot, and walks for the new ones it finds, sixteen at a time.
+__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk_new(const KernelArgs a) {
+  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  const size_t g0 = (size_t)blockIdx.x * SMX_BLOCK;
+  const size_t gid = g0 + threadIdx.x;
+  const int f = gid < total ? a.st.flags[gid] : 0;
+  const int st = gid < total ? a.st.steps[gid] : 0;
+  unsigned long long fresh = __ballot((f & SMX_F_ALIVE) && !(f & SMX_F_SOCIAL) && !(f & SMX_F_FIRST) && st == 1);
+  const int team = (int)threadIdx.x / SMX_WP_LANES, p0 = (int)threadIdx.x % SMX_WP_LANES;
+  while (fresh != 0ull) {  // uniform
+    // team t takes the t-th of the lowest sixteen set bits
+    unsigned long long rest = fresh;
+    for (int t = 0; t < team; ++t) rest &= rest - 1ull;
+    const int mine = rest != 0ull ? __ffsll((long long)rest) - 1 : -1;
+    for (int t = 0; t < SMX_BLOCK / SMX_WP_LANES; ++t) fresh &= fresh - 1ull;
+    if (mine >= 0) wp_walk_for(a, g0 + (size_t)mine, p0, false);
+  }
 }
 
 struct __align__(16) WpStageCell {  // second pass: everything of a waypoint but its position
@@ -2504,7 +2540,11 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
 // hold its whole wavefront, and its registers would set this kernel's occupancy.
 // =================================================================================
 #define SMX_WPE_KNOTS 10  // knots after the start a path lane holds in registers
-#define SMX_WPE_POOL 320  // knot records per workgroup (64 paths; loop: 48 paths of 5.5 records on average, sigma 14; 288 overflowed often)
+// knot records per workgroup (64 paths; loop: 48 paths of 5.5 records on average, sigma 14).  A workgroup whose paths need
+// more sends the teams that do not fit to the slow list, whose kernel is a launch of pure latency at the end of the tick's
+// longest chain: at 320 a dozen workgroups of 8 192 overflowed per tick (76 us each tick for 200 vehicles); two sweeps of
+// the pool inside the kernel kept the knots in registers across the sweep (256 registers, one wavefront per SIMD).
+#define SMX_WPE_POOL 352
 struct __align__(8) WpKnot {
   double x, y, h, cum;  // position, unwrapped heading, arclength from the projected start
 };
@@ -2513,7 +2553,7 @@ struct WpKnotLanes {
 };
 
 __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const int block) {
-  // 14.4 KB of LDS in all: eleven workgroups per CU (its registers allow twelve: three wavefronts per SIMD)
+  // 15.6 KB of LDS in all: ten workgroups per CU (its registers allow twelve: three wavefronts per SIMD)
   __shared__ WpKnot pool[SMX_WPE_POOL];
   __shared__ WpKnotLanes pool_lanes[SMX_WPE_POOL];
   __shared__ WpRowBook book;
@@ -2669,7 +2709,7 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     }
   }
   const int off = incl - (tabled_path ? nrec : 0);
-  if (tabled_path && off + nrec > SMX_WPE_POOL) tabled_path = false;  // the pool is full
+  if (tabled_path && off + nrec > SMX_WPE_POOL) tabled_path = false;  // the pool is full (sized so that it seldom is)
   // A team with a row the pool does not hold (more knots than the table form takes, a cut knot list, a full pool), or
   // that has to number its paths the long way (a branching inside the lookahead, a road of more than four lanes),
   // leaves all its rows and its trip meter to k_waypoints_listed: its vehicle goes to the slow list.
@@ -5120,6 +5160,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
           (void)hipStreamWaitEvent(h->side[2], h->ev_fork_slow, 0);
           hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
           hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
           slow_chain_forked = true;
         } else {
           slow_chain_pending = true;  // (one stream: after the main waypoint kernels, below)
@@ -5183,6 +5224,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
           if (slow_chain_pending) {
             hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
             hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+            if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
             slow_chain_pending = false;
           }
         } else {
@@ -5321,6 +5363,13 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       r.lidar_blocks = 0;
     }
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
+    if (!small_batch && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS) {
+      // large batches: the new vehicles' knot lists, for the next tick's k_control_fast
+      KernelArgs rn = a;
+      rn.alive_list = nullptr;
+      rn.alive_count = nullptr;
+      hipLaunchKernelGGL(k_wp_walk_new, dim3(sweep_blocks), dim3(SMX_BLOCK), 0, stream, rn);
+    }
   }
   SMX_HIP(hipGetLastError());
   if (phased) {
@@ -5369,6 +5418,17 @@ extern "C" int smx_sync(smx_handle h, void* hip_stream) {
                     "were stepped as if they had sent no action");
     }
   }
+  return SMX_OK;
+}
+
+// Developer diagnostics (not part of include/smx.h): the lengths of the last large-form tick's slow lists
+// (scan facts, scan seeds, control, waypoint rows), after a synchronisation of the device.
+extern "C" int smx_debug_slow_counts(smx_handle h, int32_t* out4) {
+  if (!h || !out4) return SMX_ERR_INVALID;
+  if (!h->slow_blob) return fail(h, SMX_ERR_STATE, "no slow lists (the map is not loaded)");
+  SMX_HIP(hipDeviceSynchronize());
+  const size_t total = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+  SMX_HIP(hipMemcpy(out4, h->slow_blob + 4 * total + 4 * (h->alive_parity ^ 1), 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
   return SMX_OK;
 }
 
