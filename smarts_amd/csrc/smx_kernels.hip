@@ -3684,6 +3684,12 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_SIDE_PRIO  // developer: side streams that get the default priority instead of the lowest (bit i = side i)
+#define SMX_SIDE_PRIO 0
+#endif
+#ifndef SMX_FACTS_EARLY_MAX  // the facts half leaves with the grid kernels up to this many vehicles, else after the seeds half
+#define SMX_FACTS_EARLY_MAX 32768
+#endif
 // orders a wavefront's own LDS traffic for the compiler (the hardware keeps a wavefront's LDS operations in order)
 #define SMX_WAVE_SYNC()                                   \
   do {                                                    \
@@ -3699,8 +3705,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
-  extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][H * W]
+// OBS observers per wavefront at a time (two while the env has at most 32 vehicles and eight tiles fit the LDS a
+// workgroup may have): lane = (observer, env-mate) for the footprints' rectangles, so that a wavefront of 32-vehicle
+// envs is full; the footprints in view are then drawn two at a time, each by a half wavefront of 8 rows x 4 columns
+// (a car ahead is 3 x 6 pixels at 0.78 m per pixel: one step), its record fetched from the lane that holds it with
+// ds_bpermute.  390 -> 1xx vector instructions per tile (a third of the headline tick's were this kernel's).
+template <int OBS>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
+  extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][OBS][H * W]
   __shared__ OgmPose pose[SMX_BLOCK];
   __shared__ unsigned char observers[SMX_BLOCK];  // the env's observing slots, compacted: the wavefronts share them evenly
   __shared__ int n_observers;                     // however many agents of the env are gone
@@ -3730,99 +3742,93 @@ __global__ void __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs
     if (lane == 0) n_observers = __popcll(om);
   }
   __syncthreads();
-  unsigned char* tile = tiles + (size_t)wave * bytes;
+  unsigned char* tile = tiles + (size_t)wave * OBS * bytes;
   const double res = c.ogm_resolution;
-  const double inv_res = 1.0 / res;  // for the pixel RECTANGLES only (an enumeration bound with a pixel of margin on
-                                     // every side); the pixel test itself keeps the oracle's arithmetic
+  const double inv_res = 1.0 / res;  // for the pixel RECTANGLES only (an enumeration bound with a margin on every
+                                     // side); the pixel test itself keeps the oracle's arithmetic
   const double hl = 0.5 * SMX_CHASSIS_LENGTH, hw = 0.5 * SMX_CHASSIS_WIDTH;
-  const int rounds = (n_observers + SMX_OGM_WAVES - 1) / SMX_OGM_WAVES;
-  // Each wavefront owns its tile and its mate list: inside the loop only lanes of ONE wavefront exchange data
-  // through LDS, whose operations a wavefront issues in order — a scheduling fence is all that is needed (four
-  // workgroup barriers per round made the four wavefronts wait for the slowest one's rectangles: 32 per env)
+  const int half = lane >> 5, in_half = lane & 31;
+  const int mate = OBS == 2 ? in_half : lane;
+  const int mate_clamped = min(mate, n_veh - 1);  // (every lane computes; lanes past the env's vehicles are masked below)
+  const int lr = in_half >> 2, lc = in_half & 3;  // this lane's pixel of a drawing step: 8 rows x 4 columns per half
+  // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res; the sums in front of `res` are
+  // exact in any order (integers and halves), so the constants are folded
+  const double col_bias = 0.5 - 0.5 * W, row_bias = 0.5 * H - 0.5;
+  const int n_obs = n_observers;
+  const int per_round = SMX_OGM_WAVES * OBS;
+  const int rounds = (n_obs + per_round - 1) / per_round;
+  // Each wavefront owns its tiles: inside the loop only lanes of ONE wavefront exchange data through LDS, whose
+  // operations a wavefront issues in order — a scheduling fence is all that is needed (four workgroup barriers per
+  // round made the four wavefronts wait for the slowest one's rectangles)
+#pragma nounroll
   for (int it = 0; it < rounds; ++it) {
-    const int turn = it * SMX_OGM_WAVES + wave;
-    const bool live = turn < n_observers;
-    const int obs = live ? (int)observers[turn] : 0;
-    if (live)
-      for (int k = lane; k < bytes / 16; k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
+    const int turn0 = (it * SMX_OGM_WAVES + wave) * OBS;  // uniform in the wavefront
+    const int n_live = min(OBS, n_obs - turn0);
+    if (n_live <= 0) break;  // (turns grow with `it`)
+    for (int k = lane; k < n_live * (bytes / 16); k += 64) reinterpret_cast<int4*>(tile)[k] = make_int4(0, 0, 0, 0);
+    const int my_turn = turn0 + (OBS == 2 ? half : 0);
+    const bool live = my_turn < n_obs;
+    const int obs = (int)observers[live ? my_turn : turn0];
+    // the footprint of vehicle `mate` in this observer's frame stays in this lane's registers (no LDS copy of it)
+    const OgmPose e = pose[obs];
+    const OgmPose v = pose[mate_clamped];
+    const double rx = e.ch, ry = e.sh;   // ego right axis
+    const double fx = -e.sh, fy = e.ch;  // ego forward axis
+    const double dx = v.x - e.x, dy = v.y - e.y;
+    const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
+    const double cm = v.ch, sm = v.sh;
+    const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
+    const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
+    // (a pixel centre inside the footprint lies inside its bounding box: columns ceil(lo) .. floor(hi).  The bounds
+    // are rounded — a dozen operations on numbers below 1e3 pixels, errors of 1e-12 — and the pixel test accepts a
+    // centre its own rounding puts on the edge: a millionth of a pixel on every side covers both.  A whole pixel of
+    // margin made a car ahead, 3 x 6 pixels, a rectangle of 5 x 8.)
+    const double slack = 1e-6;
+    // (clamped as doubles first: a mate far away must not overflow the conversion)
+    const double c_lo = fmax((cx - ext_x) * inv_res + 0.5 * W - 0.5 - slack, -1.0), c_hi = fmin((cx + ext_x) * inv_res + 0.5 * W - 0.5 + slack, (double)W);
+    const double r_lo = fmax(0.5 * H - 0.5 - (cy + ext_y) * inv_res - slack, -1.0), r_hi = fmin(0.5 * H - 0.5 - (cy - ext_y) * inv_res + slack, (double)H);
+    const int c0 = max((int)ceil(c_lo), 0), c1 = min((int)floor(c_hi), W - 1);
+    const int r0 = max((int)ceil(r_lo), 0), r1 = min((int)floor(r_hi), H - 1);
+    const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+    const bool in_view = live && mate < n_veh && v.alive != 0 && bw > 0 && bh > 0;
+    unsigned long long todo = __ballot(in_view);
     SMX_WAVE_SYNC();
-    // the footprint of vehicle `lane` in this observer's frame stays in lane `lane`'s registers; the wavefront
-    // takes the vehicles in view one by one and reads each one's record with v_readlane (no LDS copy of it:
-    // 16 KB less LDS per workgroup, so that more of them fit beside the other kernels of the tick)
-    unsigned long long todo = 0ull;
-    OgmMate mine = OgmMate{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0};
-    if (live) {
-      const OgmPose e = pose[obs];
-      const double rx = e.ch, ry = e.sh;    // ego right axis
-      const double fx = -e.sh, fy = e.ch;   // ego forward axis
-      bool in_view = false;
-      if (lane < n_veh && pose[lane].alive) {
-        const OgmPose v = pose[lane];
-        const double dx = v.x - e.x, dy = v.y - e.y;
-        const double cx = dx * rx + dy * ry, cy = dx * fx + dy * fy;  // centre in the ego frame
-        const double cm = v.ch, sm = v.sh;
-        const double vfx = cm * ry - sm * rx, vfy = sm * ry + cm * rx, vrx = cm * rx + sm * ry, vry = sm * rx - cm * ry;
-        const double ext_x = fabs(vfx) * hl + fabs(vrx) * hw, ext_y = fabs(vfy) * hl + fabs(vry) * hw;
-        // pixel centre (r, col): x = (col + 0.5 - W/2) res, y = (H/2 - (r + 0.5)) res
-        // (a pixel centre inside the footprint lies inside its bounding box: columns ceil(lo) .. floor(hi); one more
-        // on every side covers the rounding of these bounds — two more only grew the rectangles into a second 8 x 8 block)
-        int c0 = (int)ceil((cx - ext_x) * inv_res + 0.5 * W - 0.5) - 1, c1 = (int)floor((cx + ext_x) * inv_res + 0.5 * W - 0.5) + 1;
-        int r0 = (int)ceil(0.5 * H - 0.5 - (cy + ext_y) * inv_res) - 1, r1 = (int)floor(0.5 * H - 0.5 - (cy - ext_y) * inv_res) + 1;
-        c0 = max(c0, 0);
-        r0 = max(r0, 0);
-        c1 = min(c1, W - 1);
-        r1 = min(r1, H - 1);
-        if (c0 <= c1 && r0 <= r1) {
-          in_view = true;
-          mine.cx = cx;
-          mine.cy = cy;
-          mine.vfx = vfx;
-          mine.vfy = vfy;
-          mine.vrx = vrx;
-          mine.vry = vry;
-          mine.c0 = c0;
-          mine.r0 = r0;
-          mine.bw = c1 - c0 + 1;
-          mine.n_px = r1 - r0 + 1;  // (here: the rectangle's height)
-        }
-      }
-      todo = __ballot(in_view);
-    }
-    SMX_WAVE_SYNC();
-    while (todo != 0ull) {  // uniform in the wavefront
-      const int src = __ffsll((long long)todo) - 1;
+    while (todo != 0ull) {  // uniform in the wavefront: two footprints per turn, one per half
+      const int s0 = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      OgmMate q;
-      q.cx = readlane_f64(mine.cx, src);
-      q.cy = readlane_f64(mine.cy, src);
-      q.vfx = readlane_f64(mine.vfx, src);
-      q.vfy = readlane_f64(mine.vfy, src);
-      q.vrx = readlane_f64(mine.vrx, src);
-      q.vry = readlane_f64(mine.vry, src);
-      q.c0 = __builtin_amdgcn_readlane(mine.c0, src);
-      q.r0 = __builtin_amdgcn_readlane(mine.r0, src);
-      q.bw = __builtin_amdgcn_readlane(mine.bw, src);
-      q.n_px = __builtin_amdgcn_readlane(mine.n_px, src);
-      // the rectangle in 8 x 8 pixel blocks, lane = (row, column) inside a block: no division by its width
-      const int bh = q.n_px;
-      const int lr = lane >> 3, lc = lane & 7;
-      for (int rr = 0; rr < bh; rr += 8) {
-        for (int cc = 0; cc < q.bw; cc += 8) {
-          const int r = q.r0 + rr + lr, col = q.c0 + cc + lc;
-          if (rr + lr < bh && cc + lc < q.bw) {
-            const double py = (0.5 * H - (r + 0.5)) * res - q.cy;
-            const double px = (col + 0.5 - 0.5 * W) * res - q.cx;
-            if (fabs(px * q.vfx + py * q.vfy) <= hl && fabs(px * q.vrx + py * q.vry) <= hw) tile[r * W + col] = 255;
-          }
+      const int s1 = todo != 0ull ? __ffsll((long long)todo) - 1 : s0;
+      const bool two = todo != 0ull;
+      todo &= todo - 1ull;  // (0 & anything = 0)
+      const int src = half ? s1 : s0;
+      const bool drawing = half == 0 || two;
+      const double qcx = __shfl(cx, src), qcy = __shfl(cy, src);
+      const double qvfx = __shfl(vfx, src), qvfy = __shfl(vfy, src), qvrx = __shfl(vrx, src), qvry = __shfl(vry, src);
+      const int qc0 = __shfl(c0, src), qr0 = __shfl(r0, src), qbw = __shfl(bw, src), qbh = __shfl(bh, src);
+      unsigned char* dst_tile = tile + (OBS == 2 ? (src >> 5) * bytes : 0);
+      const int bh_max = max(__builtin_amdgcn_readlane(bh, s0), __builtin_amdgcn_readlane(bh, s1));
+      const int bw_max = max(__builtin_amdgcn_readlane(bw, s0), __builtin_amdgcn_readlane(bw, s1));
+      // (one step nearly always: kept from the loop optimiser, which interleaved four column steps and paid two
+      // dozen register copies per footprint for it)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+      for (int rr = 0; rr < bh_max; rr += 8) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int cc = 0; cc < bw_max; cc += 4) {
+          const int dr = rr + lr, dc = cc + lc;
+          const int r = qr0 + dr, col = qc0 + dc;
+          const double py = (row_bias - (double)r) * res - qcy;
+          const double px = ((double)col + col_bias) * res - qcx;
+          if (drawing && dr < qbh && dc < qbw && fabs(px * qvfx + py * qvfy) <= hl && fabs(px * qvrx + py * qvry) <= hw)
+            dst_tile[r * W + col] = 255;
         }
       }
     }
     SMX_WAVE_SYNC();
-    if (live) {
-      int4* dst = reinterpret_cast<int4*>(a.out.ogm + ((size_t)env * n_veh + obs) * (size_t)bytes);
-      for (int k = lane; k < bytes / 16; k += 64) dst[k] = reinterpret_cast<const int4*>(tile)[k];
+    for (int t = 0; t < n_live; ++t) {
+      const int4* src_tile = reinterpret_cast<const int4*>(tile + (size_t)t * bytes);
+      int4* dst = reinterpret_cast<int4*>(a.out.ogm + ((size_t)env * n_veh + (int)observers[turn0 + t]) * (size_t)bytes);
+      for (int k = lane; k < bytes / 16; k += 64) dst[k] = src_tile[k];
     }
-    SMX_WAVE_SYNC();  // the tile and the mate list are reused
+    SMX_WAVE_SYNC();  // the tiles are reused
   }
 }
 
@@ -4719,7 +4725,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     int prio_least = 0, prio_greatest = 0;
     SMX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     for (int i = 0; i < 3; ++i) {
-      SMX_HIP(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, prio_least));
+      SMX_HIP(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, ((SMX_SIDE_PRIO >> i) & 1) ? 0 : prio_least));
       SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -5106,8 +5112,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // OGM tiles on their own: per env (four wavefronts share the env's poses) on large batches while four
   // tiles fit a workgroup's LDS, else per observer
   auto launch_ogm = [&](hipStream_t st_, const KernelArgs& k) {
-    if (!small_batch && ogm_bytes * SMX_OGM_WAVES <= 64 * 1024)
-      hipLaunchKernelGGL(k_ogm_env, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES, st_, k);
+    if (!small_batch && c.num_vehicles <= 32 && ogm_bytes * SMX_OGM_WAVES * 2 <= 64 * 1024)
+      hipLaunchKernelGGL(k_ogm_env<2>, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES * 2, st_, k);
+    else if (!small_batch && ogm_bytes * SMX_OGM_WAVES <= 64 * 1024)
+      hipLaunchKernelGGL(k_ogm_env<1>, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES, st_, k);
     else
       hipLaunchKernelGGL(k_ogm, dim3((unsigned)total), dim3(SMX_BLOCK), ogm_bytes, st_, k);
   };
@@ -5176,7 +5184,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       // it is 4 % slower)
       // (at 32 768 vehicles — a quarter of the headline batch, one rank's shard at four GPUs — the chains are short and
       // both halves start together: 0.241 against 0.249 ms; at 65 536 the order above wins, 0.294 against 0.300)
-      if (fork && total <= 32768) {
+      if (fork && total <= SMX_FACTS_EARLY_MAX) {
         (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
       } else if (fork) {
         (void)hipEventRecord(h->ev_fork, stream);
