@@ -44,9 +44,12 @@ __device__ unsigned long long smx_prof[128];
 //  stamps then measure themselves; slot + 64 counts the reports)
 #define SMX_TACC(slot, t0, t1) \
   do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&smx_prof[slot], (t1) - (t0)); atomicAdd(&smx_prof[(slot) + 64], 1ull); } } while (0)
+#define SMX_COUNT(slot, cond) \
+  do { if (cond) atomicAdd(&smx_prof[slot], 1ull); } while (0)
 #else
 #define SMX_TSTAMP(var)
 #define SMX_TACC(slot, t0, t1)
+#define SMX_COUNT(slot, cond)
 #endif
 
 // ---------------------------------------------------------------------------------

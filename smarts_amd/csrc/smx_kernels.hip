@@ -72,6 +72,7 @@ struct KernelArgs {
   int keep_reward_done;     // auto-reset: the terminal step's reward / done / env_done stay
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
+  double nb_d2_max;         // the largest squared distance whose rounded square root is <= cfg.nb_radius (radius_threshold)
   int debug_skip;
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
   double dagm_reach;        // widest lane's half width (which segments can touch a DAGM view)
@@ -2715,6 +2716,14 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   // leaves all its rows and its trip meter to k_waypoints_listed: its vehicle goes to the slow list.
   // (so does a new vehicle, whose trip meter starts with a walk of its own: none comes here on a tick, whose new
   // vehicles are the reset pass's)
+  // (developer counts of the reasons, per path lane)
+  SMX_COUNT(50, live && p0 == 0 && long_way);
+  SMX_COUNT(51, live && p0 == 0 && branching != 0);
+  SMX_COUNT(52, my_row && !listed);
+  SMX_COUNT(53, my_row && listed && nrec == 0);
+  SMX_COUNT(54, my_row && listed && nrec > 0 && !tabled_path);
+  SMX_COUNT(55, live && p0 == 0 && (flags & SMX_F_FIRST));
+  SMX_COUNT(56, live && p0 == 0);
   int slow_i = (live && (serial_team || (my_row && !tabled_path) || (flags & SMX_F_FIRST))) ? 1 : 0;
 #pragma unroll
   for (int msk = SMX_WP_LANES / 2; msk >= 1; msk >>= 1) slow_i |= __shfl_xor(slow_i, msk, SMX_WP_LANES);
@@ -3010,63 +3019,70 @@ struct __align__(16) SharedPose {
   int pad;
 };
 
-__device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid) {
+// The rows of an agent that is gone read as an absent agent's: zeros (lane ids and slots -1).  Written by the whole
+// workgroup, thread t of nth striding each array — one lane on its own took 4 096 byte stores for an OGM tile and
+// 640 for the waypoint rows, one after the other, and the wavefront that held such a lane ended the kernel (C4: 380
+// agents go per tick, one in six wavefronts of k_observe held one: 98 us for a kernel whose wavefronts take 43).
+__device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid, int t, int nth) {
   const smx_config& c = a.cfg;
   const smx_outputs& o = a.out;
-  for (int k = 0; k < 3; ++k) o.ego_pos[gid * 3 + k] = 0.0;
-  for (int k = 0; k < SMX_EGO_F32_COUNT; ++k) o.ego_f32[gid * SMX_EGO_F32_COUNT + k] = 0.0f;
-  o.ego_lane[gid * 2] = -1;
-  o.ego_lane[gid * 2 + 1] = -1;
-  for (int k = 0; k < SMX_EV_COUNT; ++k) o.events[gid * SMX_EV_COUNT + k] = 0;
-  if (o.collidees) o.collidees[gid] = 0ull;
-  o.reward[gid] = 0.0;
-  o.dist[gid] = 0.0;
+  for (int k = t; k < 3; k += nth) o.ego_pos[gid * 3 + k] = 0.0;
+  for (int k = t; k < SMX_EGO_F32_COUNT; k += nth) o.ego_f32[gid * SMX_EGO_F32_COUNT + k] = 0.0f;
+  for (int k = t; k < 2; k += nth) o.ego_lane[gid * 2 + k] = -1;
+  for (int k = t; k < SMX_EV_COUNT; k += nth) o.events[gid * SMX_EV_COUNT + k] = 0;
+  if (t == 0) {
+    if (o.collidees) o.collidees[gid] = 0ull;
+    o.reward[gid] = 0.0;
+    o.dist[gid] = 0.0;
+  }
   if (c.sensors & SMX_SENSOR_WAYPOINTS) {
-    size_t per = (size_t)c.wp_paths * c.wp_len;
-    for (size_t k = 0; k < per; ++k) {
-      size_t q = gid * per + k;
-      o.wp_pos[q * 3] = 0.0;
-      o.wp_pos[q * 3 + 1] = 0.0;
-      o.wp_pos[q * 3 + 2] = 0.0;
+    const int per = c.wp_paths * c.wp_len;
+    for (int k = t; k < per * 3; k += nth) o.wp_pos[gid * per * 3 + k] = 0.0;
+    for (int k = t; k < per; k += nth) {
+      const size_t q = gid * per + k;
       o.wp_heading[q] = 0.0f;
       o.wp_lane_width[q] = 0.0f;
       o.wp_speed_limit[q] = 0.0f;
       o.wp_lane_index[q] = 0;
       o.wp_lane_id[q] = -1;
     }
-    for (int k = 0; k <= c.wp_paths; ++k) o.wp_count[gid * (c.wp_paths + 1) + k] = 0;
+    for (int k = t; k <= c.wp_paths; k += nth) o.wp_count[gid * (c.wp_paths + 1) + k] = 0;
   }
   if (c.sensors & SMX_SENSOR_NEIGHBORS) {
-    for (int k = 0; k < c.nb_max; ++k) {
-      size_t q = gid * c.nb_max + k;
-      o.nb_pos[q * 3] = o.nb_pos[q * 3 + 1] = o.nb_pos[q * 3 + 2] = 0.0;
-      o.nb_box[q * 3] = o.nb_box[q * 3 + 1] = o.nb_box[q * 3 + 2] = 0.0f;
+    for (int k = t; k < c.nb_max * 3; k += nth) {
+      o.nb_pos[gid * c.nb_max * 3 + k] = 0.0;
+      o.nb_box[gid * c.nb_max * 3 + k] = 0.0f;
+    }
+    for (int k = t; k < c.nb_max; k += nth) {
+      const size_t q = gid * c.nb_max + k;
       o.nb_heading[q] = 0.0f;
       o.nb_speed[q] = 0.0f;
       o.nb_lane_index[q] = 0;
       o.nb_lane_id[q] = -1;
       o.nb_slot[q] = -1;
     }
-    o.nb_count[gid] = 0;
+    if (t == 0) o.nb_count[gid] = 0;
   }
   if (c.via_max > 0 && o.via_near) {
-    for (int k = 0; k < c.via_max; ++k) o.via_near[gid * (size_t)c.via_max + k] = -1;
-    o.via_near_count[gid] = 0;
-    o.via_hit[gid] = 0;
-  }
-  if ((c.sensors & SMX_SENSOR_OGM) && o.ogm) {
-    const size_t n = (size_t)c.ogm_width * c.ogm_height;
-    for (size_t k = 0; k < n; ++k) o.ogm[gid * n + k] = 0;
-  }
-  if ((c.sensors & SMX_SENSOR_DAGM) && o.dagm) {
-    const size_t n = (size_t)c.dagm_width * c.dagm_height;
-    for (size_t k = 0; k < n; ++k) o.dagm[gid * n + k] = 0;
-  }
-  if ((c.sensors & SMX_SENSOR_LIDAR) && o.lidar_hit) {
-    for (int k = 0; k < c.lidar_rays; ++k) {
-      o.lidar_hit[gid * (size_t)c.lidar_rays + k] = 0;
-      for (int q = 0; q < 3; ++q) o.lidar_point[(gid * (size_t)c.lidar_rays + k) * 3 + q] = 0.0;
+    for (int k = t; k < c.via_max; k += nth) o.via_near[gid * (size_t)c.via_max + k] = -1;
+    if (t == 0) {
+      o.via_near_count[gid] = 0;
+      o.via_hit[gid] = 0;
     }
+  }
+  auto zero_bytes = [&](uint8_t* base, size_t n) {
+    uint8_t* p = base + gid * n;
+    if (n % 16 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      for (size_t k = t; k < n / 16; k += nth) reinterpret_cast<int4*>(p)[k] = make_int4(0, 0, 0, 0);
+    } else {
+      for (size_t k = t; k < n; k += nth) p[k] = 0;
+    }
+  };
+  if ((c.sensors & SMX_SENSOR_OGM) && o.ogm) zero_bytes(o.ogm, (size_t)c.ogm_width * c.ogm_height);
+  if ((c.sensors & SMX_SENSOR_DAGM) && o.dagm) zero_bytes(o.dagm, (size_t)c.dagm_width * c.dagm_height);
+  if ((c.sensors & SMX_SENSOR_LIDAR) && o.lidar_hit) {
+    for (int k = t; k < c.lidar_rays; k += nth) o.lidar_hit[gid * (size_t)c.lidar_rays + k] = 0;
+    for (int k = t; k < c.lidar_rays * 3; k += nth) o.lidar_point[gid * (size_t)c.lidar_rays * 3 + k] = 0.0;
   }
 }
 
@@ -3075,6 +3091,10 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid)
 // vehicles are adjacent — so a store instruction writes consecutive elements instead of one element of 64 rows.
 // (Scalars per agent — done, active, reward, counts — are consecutive across lanes as they are.)
 #define SMX_NB_STAGE 16  // neighbour rows per agent the staged form handles (nb_max; StdObs keeps 10)
+// floor(e / d) for 0 <= e < 4096, 1 <= d <= 64, rcp = 1.0f / d: (e + 0.5) / d is at least 0.5 / d away from an integer,
+// the float32 product is off by less than 4096 / d * 2^-22
+__device__ __forceinline__ int small_quotient(int e, float rcp) { return (int)(((float)e + 0.5f) * rcp); }
+static_assert(SMX_BLOCK * SMX_NB_STAGE * 3 < 4096, "small_quotient's range");
 struct ObsStage {
   float ego_f32[SMX_BLOCK][SMX_EGO_F32_COUNT];
   short ego_lane[SMX_BLOCK][2];
@@ -3087,12 +3107,14 @@ struct ObsStage {
 __device__ __forceinline__ void observe_role(const KernelArgs& a, const int block) {
   __shared__ SharedPose pose[SMX_BLOCK];
   __shared__ ObsStage stage;
+  __shared__ unsigned long long zero_mask;  // vehicles of the workgroup whose rows are to read as an absent agent's
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const smx_outputs& o = a.out;
   const int n_veh = c.num_vehicles;
   const int epb = SMX_BLOCK / n_veh;
   const int local = threadIdx.x;
+  if (local == 0) zero_mask = 0ull;
   const int env_local = local / n_veh;
   const int slot = local - env_local * n_veh;
   const int env = block * epb + env_local;
@@ -3147,7 +3169,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   int new_flags = flags;  // what the commit kernel makes the vehicle's flags word after this pass
   if (valid && alive && social && first) {
     // nothing to observe: its rows read as an absent agent's
-    zero_dense_rows(a, gid);
+    atomicOr(&zero_mask, 1ull << local);
     o.active[gid] = 0;
     o.done[gid] = 0;
     new_flags = flags & ~SMX_F_FIRST;
@@ -3163,19 +3185,32 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     // ---- collisions (smarts.py:1270-1291): a new vehicle has not been through a physics step
     bool collided = false;
     unsigned long long collidee_mask = 0ull;
-    if (!first && !SMX_SKIP(a, 4)) {
-      // broad phase over all env-mates first (circumscribed circles), narrow phase only over the
-      // survivors: a wavefront then pays for max-over-lanes(candidates) box tests, not for n_veh
+    // One pass over the env-mates serves the collisions' broad phase (circumscribed circles; the narrow phase then
+    // runs over the survivors only: a wavefront pays for max-over-lanes(candidates) box tests, not for n_veh) and
+    // the neighbourhood (sensors.py:241-266, smarts.py:1191-1208: every other vehicle of the instance within
+    // `radius`, in slot order, first nb_max kept) — both look at the same squared distance.
+    const bool want_col = !first && !SMX_SKIP(a, 4);
+    const bool want_nb = (c.sensors & SMX_SENSOR_NEIGHBORS) && !SMX_SKIP(a, 8);
+    const bool nb_in_pass = want_nb && nb_staged;  // (more rows than the staged form holds: the loop further down)
+    int nb_cnt = 0;
+    {
       unsigned long long cand = 0ull;
       const double reach = sqrt(SMX_CHASSIS_LENGTH * SMX_CHASSIS_LENGTH + SMX_CHASSIS_WIDTH * SMX_CHASSIS_WIDTH) +
                            SMX_COLLISION_LEEWAY;
+      const double reach2 = reach * reach;
+      const bool nb_all = !(c.nb_radius >= 0.0);
       for (int j = 0; j < n_veh; ++j) {
         if (j == slot) continue;
         const SharedPose& q = env_pose[j];
         if (!q.alive) continue;
         const double dx = px - q.x, dy = py - q.y;
-        if (dx * dx + dy * dy > reach * reach) continue;
-        cand |= 1ull << j;
+        const double d2 = dx * dx + dy * dy;
+        if (want_col && !(d2 > reach2)) cand |= 1ull << j;
+        // sqrt(dx^2 + dy^2 + 0^2) <= radius, as a threshold on the squared distance (radius_threshold)
+        if (nb_in_pass && (nb_all || d2 <= a.nb_d2_max)) {
+          if (nb_cnt < c.nb_max) stage.nb_list[local][nb_cnt] = (signed char)j;
+          ++nb_cnt;
+        }
       }
       const double my_h = wrap_heading(s.heading);
       // one Collision per collidee (smarts.py:1270-1291): every survivor is tested, not just the first hit
@@ -3247,11 +3282,10 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
       }
     }
 
-    // ---- neighbourhood (sensors.py:241-266, smarts.py:1191-1208): every other vehicle of the
-    //      instance within `radius` (3-D distance), in slot order, first nb_max kept
-    if ((c.sensors & SMX_SENSOR_NEIGHBORS) && !SMX_SKIP(a, 8)) {
-      int cnt = 0;
-      for (int j = 0; j < n_veh; ++j) {
+    // ---- neighbourhood: the staged form's rows were listed above; more rows than it holds leave from here
+    if (want_nb) {
+      int cnt = nb_cnt;
+      for (int j = 0; j < n_veh && !nb_staged; ++j) {
         if (j == slot) continue;
         const SharedPose& q = env_pose[j];
         if (!q.alive) continue;
@@ -3260,9 +3294,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
           double d = sqrt(dx * dx + dy * dy + dz * dz);
           if (!(d <= c.nb_radius)) continue;
         }
-        if (cnt < c.nb_max && nb_staged) {
-          stage.nb_list[local][cnt] = (signed char)j;
-        } else if (cnt < c.nb_max) {
+        if (cnt < c.nb_max) {
           size_t w = gid * c.nb_max + cnt;
           o.nb_pos[w * 3 + 0] = q.x;
           o.nb_pos[w * 3 + 1] = q.y;
@@ -3448,7 +3480,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     }
     // an agent whose vehicle is gone: absent from the observations (zeros), done stays 0
     if (!alive && (o.active[gid] != 0 || o.done[gid] != 0)) {
-      zero_dense_rows(a, gid);
+      atomicOr(&zero_mask, 1ull << local);
       o.done[gid] = 0;
       o.active[gid] = 0;
     }
@@ -3456,8 +3488,14 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   if (valid) a.st.facts_i32[(size_t)SMX_FI_FLAGS_NEXT * total + gid] = new_flags;
   // ---- copy-out of the staged rows, every array in memory order over the workgroup's vehicles
   __syncthreads();
+  SMX_TSTAMP(to2c);
   {
     const int nth = (int)blockDim.x;
+    for (unsigned long long zm = zero_mask; zm != 0ull; zm &= zm - 1ull)  // (uniform in the workgroup)
+      zero_dense_rows(a, (size_t)block * epb * n_veh + (__ffsll((long long)zm) - 1), local, nth);
+    // (element -> vehicle, row: quotients by the run-time row lengths, below 4096 / by at most 64 — exact in float32
+    // with half a unit added; an integer division is some forty instructions, and these sweeps were half the kernel)
+    const float rcp_veh = 1.0f / (float)n_veh;
     const int wg_veh = epb * n_veh;                           // vehicles of this workgroup (<= 64), gids g0 ...
     const size_t g0 = (size_t)block * epb * n_veh;
     for (int e = local; e < wg_veh * 3; e += nth) {           // ego_pos
@@ -3477,21 +3515,22 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
     }
     if ((c.sensors & SMX_SENSOR_NEIGHBORS) && nb_staged && !SMX_SKIP(a, 8)) {
       const int K = c.nb_max;
+      const float rcp_k3 = 1.0f / (float)(K * 3), rcp_k = 1.0f / (float)K;
       for (int e = local; e < wg_veh * K * 3; e += nth) {     // nb_pos, nb_box
-        const int v = e / (K * 3), r = e - v * (K * 3), k = r / 3, q = r - k * 3;
+        const int v = small_quotient(e, rcp_k3), r = e - v * (K * 3), k = r / 3, q = r - k * 3;
         if (!stage.mode[v]) continue;
         const bool held = k < (int)stage.nb_kept[v];
-        const SharedPose& P = pose[(v / n_veh) * n_veh + (held ? (int)stage.nb_list[v][k] : 0)];
+        const SharedPose& P = pose[small_quotient(v, rcp_veh) * n_veh + (held ? (int)stage.nb_list[v][k] : 0)];
         o.nb_pos[g0 * K * 3 + e] = held ? (q == 0 ? P.x : (q == 1 ? P.y : SMX_BASE_HEIGHT)) : 0.0;
         o.nb_box[g0 * K * 3 + e] =
             held ? (float)(q == 0 ? SMX_CHASSIS_LENGTH : (q == 1 ? SMX_CHASSIS_WIDTH : SMX_CHASSIS_HEIGHT)) : 0.0f;
       }
       for (int e = local; e < wg_veh * K; e += nth) {         // the scalar neighbour rows
-        const int v = e / K, k = e - v * K;
+        const int v = small_quotient(e, rcp_k), k = e - v * K;
         if (!stage.mode[v]) continue;
         const bool held = k < (int)stage.nb_kept[v];
         const int j = held ? (int)stage.nb_list[v][k] : 0;
-        const SharedPose& P = pose[(v / n_veh) * n_veh + j];
+        const SharedPose& P = pose[small_quotient(v, rcp_veh) * n_veh + j];
         const size_t w = g0 * K + e;
         o.nb_heading[w] = held ? (float)P.heading : 0.0f;
         o.nb_speed[w] = held ? (float)P.speed : 0.0f;
@@ -3503,6 +3542,7 @@ __device__ __forceinline__ void observe_role(const KernelArgs& a, const int bloc
   }
   SMX_TSTAMP(to3);
   SMX_TACC(6, to0, to3);
+  SMX_TACC(45, to2c, to3);
 }
 
 // =================================================================================
@@ -4343,6 +4383,24 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_reset_env(const KernelArgs a) {
 // =================================================================================
 // C-ABI (include/smx.h)
 // =================================================================================
+// sqrt(d2) <= radius without the square root: the correctly rounded root does not decrease with its argument, so
+// the test holds exactly for the squared distances up to a threshold — the largest double whose rounded root is
+// still <= radius (found from radius * radius by stepping a few units in the last place).  k_observe takes the
+// 32 x 32 distances of an env per tick; the root and its comparison were twenty instructions each.
+static double radius_threshold(double radius) {
+  if (!(radius >= 0.0)) return -1.0;           // (unlimited: the kernels do not look at it)
+  if (std::isinf(radius)) return radius;
+  double t = radius * radius;
+  if (std::isinf(t)) return t;
+  while (t > 0.0 && std::sqrt(t) > radius) t = std::nextafter(t, 0.0);
+  for (;;) {
+    const double up = std::nextafter(t, INFINITY);
+    if (std::isinf(up) || !(std::sqrt(up) <= radius)) break;
+    t = up;
+  }
+  return t;
+}
+
 struct smx_handle_s {
   smx_config cfg;
   int device;
@@ -4374,6 +4432,7 @@ struct smx_handle_s {
   std::vector<int32_t> host_lane_road, host_lane_out_off, host_lane_out_idx;  // kept for smx_set_missions
   MissionsDev missions;
   double heading_gain_pos, lateral_gain_pos;
+  double nb_d2_max;
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
   int launch_strategy;  // SMX_LAUNCH_*
@@ -4461,6 +4520,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   // for the sedan they saturate at (0.04, 3.4) for both Lane-space target speeds.
   h->heading_gain_pos = 0.04;
   h->lateral_gain_pos = 3.4;
+  h->nb_d2_max = radius_threshold(h->cfg.nb_radius);
   h->timing = false;
   h->ev_used = 0;
   h->phase_timing = false;
@@ -5043,6 +5103,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.keep_reward_done = 0;
   a.reset_all = 0;
   a.heading_gain_pos = h->heading_gain_pos;
+  a.nb_d2_max = h->nb_d2_max;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
   a.knots = h->knots;

@@ -1,5 +1,5 @@
-"""Developer: wave-clock stamps of the large form's kernels (library built with -DSMX_DEBUG_TIMING: python -m smarts_amd.build --prof).
-    python tools/dev_phase_prof2.py [c4]"""
+"""Developer: why vehicles reach k_waypoints_emit's slow list (library built with -DSMX_DEBUG_TIMING: python -m smarts_amd.build --prof).
+    python tools/dev_slow_reasons.py [c4] [ticks]"""
 import os, sys, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,7 @@ from smarts_amd.map_compiler import compile_map
 from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
 from smarts_amd import _native as nat
 config = sys.argv[1] if len(sys.argv) > 1 else "c4"
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 preset, scenario, cfg_kw = bench.workload_config(config)
 E, N = cfg_kw["num_envs"], cfg_kw["num_vehicles"]
 cm = compile_map(load_net(os.path.join(ROOT, 'smarts_amd/scenarios', scenario)))
@@ -17,17 +18,10 @@ sim = BatchedSim(cm, SimConfig(**cfg_kw), spawns=make_spawns(cm, E, N, episodes=
 actions = torch.from_numpy(bench.action_stream(E, N, 42, 0)).cuda()
 sim.reset()
 for i in range(10): sim.step(actions[i % bench.ACTION_CYCLE])
-sim.set_timing(2)  # serial: one kernel at a time
 torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 128)(); lib.smx_prof_read(buf, 1)
-T = 30
 for i in range(T): sim.step(actions[(10 + i) % bench.ACTION_CYCLE])
 torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
-V = E * N
-names = {6: ('observe: total', V), 7: ('observe: prologue (loads, pose block)', V), 8: ('observe: collisions, ego rows, neighbours', V), 45: ('observe: copy-out', V),
-         32: ('emit: prologue loads', V * 4), 33: ('emit: knot walk', V * 4), 34: ('emit: prefix sum, book, pool writes', V * 4), 35: ('emit: slots loop', V * 4), 36: ('emit: trip meter', V * 4), 37: ('emit: total', V * 4),
-         38: ('emit: a round of 4 slots, arithmetic', V * 4 * 5), 39: ('emit: a round of 4 slots, fixups + stores', V * 4 * 5),
-         40: ('facts: setup + pass 1', V), 41: ('facts: pass 2', V), 42: ('facts: heading candidates', V), 43: ('facts: two lane positions', V), 44: ('facts: trig', V)}
+names = {50: 'teams on a road of more than four lanes', 51: 'teams with a branching inside the lookahead', 52: 'rows whose knot list was cut (nk > cap)',
+         53: 'rows with more knots than a path lane holds', 54: 'rows the pool had no room for', 55: 'new vehicles', 56: 'live teams'}
 for k in sorted(names):
-    nm, lanes = names[k]
-    if buf[k + 64]:
-        print(f'{nm:44s} {buf[k] / buf[k + 64] / 100.0:10.2f} us per report  ({buf[k + 64] / T:.0f} reports per tick)')
+    print(f'{names[k]:52s} {buf[k] / T:10.2f} per tick')
