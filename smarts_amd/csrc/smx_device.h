@@ -46,10 +46,21 @@ __device__ unsigned long long smx_prof[128];
   do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&smx_prof[slot], (t1) - (t0)); atomicAdd(&smx_prof[(slot) + 64], 1ull); } } while (0)
 #define SMX_COUNT(slot, cond) \
   do { if (cond) atomicAdd(&smx_prof[slot], 1ull); } while (0)
+// a wavefront's whole span in a kernel, every wavefront its own word (no atomics: 8 192 of them on one address take
+// longer than the kernel): the kernel ends with its slowest wavefront
+#define SMX_SPAN_KERNELS 8
+#define SMX_SPAN_WAVES 16384
+__device__ unsigned int smx_span[SMX_SPAN_KERNELS * SMX_SPAN_WAVES];
+#define SMX_TSPAN(slot, t0, t1)                                                                       \
+  do {                                                                                                \
+    const unsigned w__ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                         \
+    if ((threadIdx.x & 63) == 0 && w__ < SMX_SPAN_WAVES) smx_span[(slot) * SMX_SPAN_WAVES + w__] = (unsigned int)((t1) - (t0)); \
+  } while (0)
 #else
 #define SMX_TSTAMP(var)
 #define SMX_TACC(slot, t0, t1)
 #define SMX_COUNT(slot, cond)
+#define SMX_TSPAN(slot, t0, t1)
 #endif
 
 // ---------------------------------------------------------------------------------

@@ -72,6 +72,7 @@ struct KernelArgs {
   int keep_reward_done;     // auto-reset: the terminal step's reward / done / env_done stay
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
+  int walk_new;             // k_first: also walk the new vehicles' knot lists (large batches: for the next tick's k_control_fast)
   double nb_d2_max;         // the largest squared distance whose rounded square root is <= cfg.nb_radius (radius_threshold)
   int debug_skip;
   int wp_blocks, obs_blocks, lidar_blocks;  // k_sensors: workgroups per role (OGM takes the rest)
@@ -984,6 +985,7 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, c
 // =================================================================================
 template <int SPACE>
 __global__ void __launch_bounds__(SMX_BLOCK) k_control_fast(const KernelArgs a) {
+  SMX_TSTAMP(span0);
   // the wanted path's waypoints, [element][lane]: 17 headings, then x and y of the first ten (lane_following_from_path
   // reads no position beyond waypoint 9).  19 KB: eight workgroups per CU, every vehicle of 131 k resident at once — at
   // 26 KB (all 51 elements) six fit, and the kernel ran a second round for a quarter of its workgroups.
@@ -1258,6 +1260,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_control_fast(const KernelArgs a) 
     base = __shfl(base, __ffsll((long long)mask) - 1);
     if (slow) a.slow_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
   }
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(0, span0, span1);
 }
 
 // =================================================================================
@@ -1495,6 +1499,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __lau
 // length of the searches from scratch.
 template <int ROLE>
 __global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
+  SMX_TSTAMP(span0);
   __shared__ int cand_lds[(ROLE == 0 ? SMX_FACTS_CAND : SMX_SEEDS_CAND) * SMX_BLOCK];
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
@@ -1600,6 +1605,8 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
     base = __shfl(base, __ffsll((long long)mask) - 1);
     if (slow) a.slow_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gid;
   }
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(ROLE == 1 ? 1 : 2, span0, span1);
 }
 
 // k_scan_half over a list whose length is only known on the device (the slow list): a fixed grid, teams striding it
@@ -2100,7 +2107,8 @@ __global__ void __launch_bounds__(SMX_ALIVE_BLOCK) k_alive_list(const KernelArgs
 // the seed lane's first path and the number of paths that start there (KnotLists).
 // (`honour_pending`: pass over a vehicle whose seeds the slow chain is still looking for — k_scan_fast; the slow chain's
 // own walk and the walk of the reset pass's new vehicles take every vehicle they are given)
-__device__ __forceinline__ void wp_walk_for(const KernelArgs& a, const size_t gid, const int p0, const bool honour_pending) {
+__device__ __forceinline__ void wp_walk_for(const KernelArgs& a, const size_t gid, const int p0, const bool honour_pending,
+                                            const bool whatever_the_pass = false) {
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
@@ -2112,7 +2120,7 @@ __device__ __forceinline__ void wp_walk_for(const KernelArgs& a, const size_t gi
   double D = 0.0;
   // (nothing of a pending vehicle's lists is touched here: the slow chain writes them meanwhile, on another stream)
   if (honour_pending && a.seed_pending != nullptr && a.seed_pending[gid]) return;
-  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || (flags & SMX_F_FIRST))) {
+  if ((flags & SMX_F_ALIVE) && !(flags & SMX_F_SOCIAL) && (!a.first_only || whatever_the_pass || (flags & SMX_F_FIRST))) {
     const PathSeeds seed = load_seeds(a, gid, total);
     if (seed.road >= 0 && seed.n_lanes <= SMX_WP_LANES && p0 < seed.n_lanes) {
       const double px = SF(SMX_S_X), py = SF(SMX_S_Y);
@@ -2175,9 +2183,12 @@ __device__ __forceinline__ void wp_walk_for(const KernelArgs& a, const size_t gi
 }
 
 __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk(const KernelArgs a) {
+  SMX_TSTAMP(span0);
   const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
   const size_t lane_no = (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x;
   wp_walk_for(a, launch_vehicle(a, lane_no / SMX_WP_LANES, total), (int)(lane_no % SMX_WP_LANES), true);
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(3, span0, span1);
 }
 
 // the slow chain's vehicles (their seeds come from k_scan_listed): a fixed grid striding the slow list.  Their rows
@@ -2187,28 +2198,6 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk_listed(const KernelArgs a
   constexpr int VPB = SMX_BLOCK / SMX_WP_LANES;
   for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
     wp_walk_for(a, (size_t)a.slow_list[i], (int)threadIdx.x % SMX_WP_LANES, false);
-}
-
-// the vehicles the reset pass has just created (k_first: steps == 1, SMX_F_FIRST already cleared): their knot lists,
-// so that the next tick's k_control_fast serves them too (a new vehicle without lists went through the slow
-// controller, two launches of pure latency in front of everything else of the tick).  A workgroup looks at the
-// words of 64 vehicles with one load and a ballot, and walks for the new ones it finds, sixteen at a time.
-__global__ void __launch_bounds__(SMX_BLOCK) k_wp_walk_new(const KernelArgs a) {
-  const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
-  const size_t g0 = (size_t)blockIdx.x * SMX_BLOCK;
-  const size_t gid = g0 + threadIdx.x;
-  const int f = gid < total ? a.st.flags[gid] : 0;
-  const int st = gid < total ? a.st.steps[gid] : 0;
-  unsigned long long fresh = __ballot((f & SMX_F_ALIVE) && !(f & SMX_F_SOCIAL) && !(f & SMX_F_FIRST) && st == 1);
-  const int team = (int)threadIdx.x / SMX_WP_LANES, p0 = (int)threadIdx.x % SMX_WP_LANES;
-  while (fresh != 0ull) {  // uniform
-    // team t takes the t-th of the lowest sixteen set bits
-    unsigned long long rest = fresh;
-    for (int t = 0; t < team; ++t) rest &= rest - 1ull;
-    const int mine = rest != 0ull ? __ffsll((long long)rest) - 1 : -1;
-    for (int t = 0; t < SMX_BLOCK / SMX_WP_LANES; ++t) fresh &= fresh - 1ull;
-    if (mine >= 0) wp_walk_for(a, g0 + (size_t)mine, p0, false);
-  }
 }
 
 struct __align__(16) WpStageCell {  // second pass: everything of a waypoint but its position
@@ -3752,6 +3741,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // ds_bpermute.  390 -> 1xx vector instructions per tile (a third of the headline tick's were this kernel's).
 template <int OBS>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(SMX_OGM_WAVES * 64) k_ogm_env(const KernelArgs a) {
+  SMX_TSTAMP(span0);
   extern __shared__ __align__(16) unsigned char tiles[];  // [SMX_OGM_WAVES][OBS][H * W]
   __shared__ OgmPose pose[SMX_BLOCK];
   __shared__ unsigned char observers[SMX_BLOCK];  // the env's observing slots, compacted: the wavefronts share them evenly
@@ -3870,6 +3860,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(SMX
     }
     SMX_WAVE_SYNC();  // the tiles are reused
   }
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(6, span0, span1);
 }
 
 // =================================================================================
@@ -4138,6 +4130,21 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
   __syncthreads();
   // ---- commit
   commit_role(a, block);
+  // ---- large batches: the new vehicles' knot lists, so that the next tick's k_control_fast serves them too (a new
+  // vehicle without lists went through the slow controller, two launches of pure latency in front of everything else
+  // of the tick).  New here: alive, SMX_F_FIRST just cleared by the commit, one step old.
+  if (a.walk_new) {
+    __threadfence();
+    __syncthreads();
+    for (size_t base = g0; base < g1; base += SMX_FIRST_BLOCK / SMX_WP_LANES) {
+      const size_t gid = base + threadIdx.x / SMX_WP_LANES;
+      if (gid >= g1) continue;
+      const int f = a.st.flags[gid];
+      if ((f & SMX_F_ALIVE) && !(f & SMX_F_SOCIAL) && !(f & SMX_F_FIRST) && a.st.steps[gid] == 1) {
+        wp_walk_for(a, gid, (int)threadIdx.x % SMX_WP_LANES, false, true);  // (the reset pass's flag word says "new vehicles only")
+      }
+    }
+  }
 }
 
 // single-role launches: large batches (each role then keeps its own register / LDS footprint and
@@ -4300,7 +4307,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_grid_first(const KernelArgs a) {
 }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints(const KernelArgs a) { waypoints_role(a, (int)blockIdx.x); }
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_tables(const KernelArgs a) { waypoints_tables_role(a, (int)blockIdx.x); }
-__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_emit(const KernelArgs a) { waypoints_emit_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_emit(const KernelArgs a) {
+  SMX_TSTAMP(span0);
+  waypoints_emit_role(a, (int)blockIdx.x);
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(4, span0, span1);
+}
 // the vehicles k_waypoints_emit left on the slow list: waypoints_for (a team of four lanes per vehicle), a fixed grid
 // striding the list, whose length is only known on the device
 __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_listed(const KernelArgs a) {
@@ -4311,7 +4323,12 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_listed(const KernelArgs
     waypoints_for<SMX_BLOCK>(a, (size_t)a.slow_list[i], knot_scratch + threadIdx.x);
 }
 // (capped at 168 registers for a third wavefront per SIMD beside the waypoint kernels it spills 52 of them: 0.796 -> 0.806 ms)
-__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) { observe_role(a, (int)blockIdx.x); }
+__global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
+  SMX_TSTAMP(span0);
+  observe_role(a, (int)blockIdx.x);
+  SMX_TSTAMP(span1);
+  SMX_TSPAN(5, span0, span1);
+}
 __global__ void __launch_bounds__(SMX_BLOCK) k_lidar(const KernelArgs a) { lidar_role(a, (int)blockIdx.x); }
 // The lidar of the reset pass on large batches: almost no vehicle is new in a given tick, and when an env restarts
 // all its vehicles are — neighbours in memory.  Workgroup w looks at the vehicles v = w (mod gridDim.x), 64 flags per
@@ -4422,7 +4439,7 @@ struct smx_handle_s {
   // disjoint rows) and are bound by different things — waypoint chain walks by load latency, OGM tiles by
   // their own write stream — so they are enqueued on side streams between two events and overlap.
   hipStream_t side[3];
-  hipEvent_t ev_fork, ev_fork_grid, ev_fork_slow, ev_join[3];
+  hipEvent_t ev_fork, ev_fork_grid, ev_join[3];
   bool side_ready;
   const double* lidar_rays;
   smx_via* vias_dev;
@@ -4461,6 +4478,11 @@ static int fail(smx_handle h, int code, const std::string& msg) {
 extern "C" const char* smx_version(void) { return "smarts-mi355x 0.1 (gfx950)"; }
 
 #ifdef SMX_DEBUG_TIMING
+extern "C" int smx_span_read(unsigned int* out) {  // developer: [kernel][wavefront] spans of the last launches, 10 ns units
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_span), sizeof(unsigned int) * SMX_SPAN_KERNELS * SMX_SPAN_WAVES) != hipSuccess) return -2;
+  return 0;
+}
+
 extern "C" int smx_prof_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(smx_prof), 128 * sizeof(unsigned long long)) != hipSuccess) return -2;
   if (reset) {
@@ -4789,7 +4811,6 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
       SMX_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    SMX_HIP(hipEventCreateWithFlags(&h->ev_fork_slow, hipEventDisableTiming));
     SMX_HIP(hipEventCreateWithFlags(&h->ev_fork_grid, hipEventDisableTiming));
     h->side_ready = true;
   }
@@ -5104,6 +5125,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.reset_all = 0;
   a.heading_gain_pos = h->heading_gain_pos;
   a.nb_d2_max = h->nb_d2_max;
+  a.walk_new = 0;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
   a.knots = h->knots;
@@ -5191,7 +5213,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     const bool fork = !small_batch && !phased && h->side_ready;
     hipStream_t s_grid = stream, s_obs = stream;
     KernelArgs kf = k, ks = k, kwp = k;  // (kwp: the waypoint kernels, which pass over the slow chain's vehicles)
-    bool slow_chain_forked = false, slow_chain_pending = false;
+    bool slow_chain_forked = false, slow_chain_pending = false, seeds_fork_recorded = false;
     if (fork) {
       (void)hipEventRecord(h->ev_fork_grid, stream);
       (void)hipStreamWaitEvent(h->side[0], h->ev_fork_grid, 0);
@@ -5225,8 +5247,11 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         if (fork) {
           // the slow chain — the few vehicles whose seeds take the searches from scratch, then their walks and rows by the
           // serial emitter — runs beside the main chain (k_wp_walk -> k_waypoints_emit pass over those vehicles)
-          (void)hipEventRecord(h->ev_fork_slow, stream);
-          (void)hipStreamWaitEvent(h->side[2], h->ev_fork_slow, 0);
+          // (one event after the seeds half serves this fork and the facts half's below: every record on the caller's
+          // stream is a packet its next kernel waits behind, ten microseconds of the tick's longest chain)
+          (void)hipEventRecord(h->ev_fork, stream);
+          seeds_fork_recorded = true;
+          (void)hipStreamWaitEvent(h->side[2], h->ev_fork, 0);
           hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
           hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
           if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
@@ -5248,7 +5273,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       if (fork && total <= SMX_FACTS_EARLY_MAX) {
         (void)hipStreamWaitEvent(h->side[1], h->ev_fork_grid, 0);
       } else if (fork) {
-        (void)hipEventRecord(h->ev_fork, stream);
+        if (!seeds_fork_recorded) (void)hipEventRecord(h->ev_fork, stream);
         (void)hipStreamWaitEvent(h->side[1], h->ev_fork, 0);
       }
       if (fast) {
@@ -5431,14 +5456,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       hipLaunchKernelGGL(k_lidar_first, dim3((unsigned)std::min<size_t>(SMX_LIDAR_FIRST_BLOCKS, total)), dim3(SMX_BLOCK), 0, stream, r);
       r.lidar_blocks = 0;
     }
+    // large batches: k_first also walks the new vehicles' knot lists, for the next tick's k_control_fast
+    r.walk_new = (!small_batch && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS) ? 1 : 0;
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
-    if (!small_batch && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS) {
-      // large batches: the new vehicles' knot lists, for the next tick's k_control_fast
-      KernelArgs rn = a;
-      rn.alive_list = nullptr;
-      rn.alive_count = nullptr;
-      hipLaunchKernelGGL(k_wp_walk_new, dim3(sweep_blocks), dim3(SMX_BLOCK), 0, stream, rn);
-    }
   }
   SMX_HIP(hipGetLastError());
   if (phased) {
@@ -5569,7 +5589,6 @@ extern "C" void smx_destroy(smx_handle h) {
       (void)hipEventDestroy(h->ev_join[i]);
     }
     (void)hipEventDestroy(h->ev_fork);
-    (void)hipEventDestroy(h->ev_fork_slow);
     (void)hipEventDestroy(h->ev_fork_grid);
   }
   if (h->vias_dev) (void)hipFree(h->vias_dev);
