@@ -49,7 +49,7 @@
 #ifndef SMX_WP_STAGED
 #define SMX_WP_STAGED 0             // developer variant (-DSMX_WP_STAGED=1): k_waypoints_tables instead of k_waypoints_emit
 #endif
-#define SMX_SLOW_BLOCKS 512          // workgroups of k_scan_listed (the slow list's length is only known on the device)
+#define SMX_SLOW_BLOCKS 512          // workgroups of the slow lists' kernels on a map without junctions (smx_load_map: slow_blocks)
 #ifndef SMX_SCAN_UNSEEDED
 #define SMX_SCAN_UNSEEDED 0         // developer variant (-DSMX_SCAN_UNSEEDED=1): the scan never starts from last tick's answers
 #endif
@@ -4450,6 +4450,7 @@ struct smx_handle_s {
   MissionsDev missions;
   double heading_gain_pos, lateral_gain_pos;
   double nb_d2_max;
+  int slow_blocks;  // grid of the slow lists' kernels (smx_load_map)
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
   int launch_strategy;  // SMX_LAUNCH_*
@@ -4543,6 +4544,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->heading_gain_pos = 0.04;
   h->lateral_gain_pos = 3.4;
   h->nb_d2_max = radius_threshold(h->cfg.nb_radius);
+  h->slow_blocks = SMX_SLOW_BLOCKS;
   h->timing = false;
   h->ev_used = 0;
   h->phase_timing = false;
@@ -4675,6 +4677,19 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     if (t->road_par_idx[i] < 0 || t->road_par_idx[i] >= t->n_roads) return fail(h, SMX_ERR_INVALID, "parallel road out of range");
   h->dagm_reach = 0.0;
   for (size_t i = 0; i < nl; ++i) h->dagm_reach = std::max(h->dagm_reach, 0.5 * t->lane_width[i]);
+  // The slow lists' kernels run a fixed grid that strides a list whose length only the device knows.  On a map
+  // without junctions the lists hold a few vehicles of a hundred thousand and the grid is an empty launch's latency;
+  // where lanes branch or cross, a third of the vehicles is on them (minicity, 262 144 vehicles: 77 000 rows through
+  // 512 workgroups were half a wavefront per SIMD for nine passes, 1.4 ms of a 2.8 ms tick) — a team slot for every
+  // second vehicle then.
+  {
+    bool junctions = false;
+    for (size_t i = 0; i < nl && !junctions; ++i) junctions = t->lane_in_junction[i] != 0;
+    const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+    const size_t teams_per_block = SMX_BLOCK / SMX_WP_LANES;
+    h->slow_blocks = SMX_SLOW_BLOCKS;
+    if (junctions) h->slow_blocks = (int)std::min<size_t>(8192, std::max<size_t>(SMX_SLOW_BLOCKS, tv / (2 * teams_per_block)));
+  }
 #define ADD(field, count, type) size_t off_##field = w.add(t->field, (size_t)(count) * sizeof(type))
   ADD(lane_road, nl, int32_t);
   ADD(lane_index, nl, int32_t);
@@ -5252,9 +5267,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
           (void)hipEventRecord(h->ev_fork, stream);
           seeds_fork_recorded = true;
           (void)hipStreamWaitEvent(h->side[2], h->ev_fork, 0);
-          hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
-          hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
-          if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          hipLaunchKernelGGL(k_scan_listed<1>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          hipLaunchKernelGGL(k_waypoints_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
           slow_chain_forked = true;
         } else {
           slow_chain_pending = true;  // (one stream: after the main waypoint kernels, below)
@@ -5278,7 +5293,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       }
       if (fast) {
         hipLaunchKernelGGL(k_scan_fast<0>, dim3(fast_blocks), dim3(SMX_BLOCK), 0, s_obs, kf);
-        hipLaunchKernelGGL(k_scan_listed<0>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, s_obs, kf);
+        hipLaunchKernelGGL(k_scan_listed<0>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, s_obs, kf);
       } else
         hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
       // (holding the grid kernels back as well was slower: 0.81 -> 0.85 ms; they overlap the seeds half)
@@ -5314,11 +5329,11 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
           kw.slow_list = h->slow_blob + 3 * total;
           kw.slow_count = h->slow_blob + 4 * total + 4 * slow_parity + 3;
           hipLaunchKernelGGL(k_waypoints_emit, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, kw);
-          hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, kw);
+          hipLaunchKernelGGL(k_waypoints_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, kw);
           if (slow_chain_pending) {
-            hipLaunchKernelGGL(k_scan_listed<1>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
-            hipLaunchKernelGGL(k_waypoints_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
-            if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ks);
+            hipLaunchKernelGGL(k_scan_listed<1>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ks);
+            hipLaunchKernelGGL(k_waypoints_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ks);
+            if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ks);
             slow_chain_pending = false;
           }
         } else {
@@ -5374,8 +5389,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       case SMX_ACTION_SPACE_LANE:
         if (fast_scan && h->slow_blob) {  // one lane per vehicle; the rest through the slow list (k_control_fast)
           hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
-          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
-          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
         } else {
           hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
           hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
@@ -5384,8 +5399,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
         if (fast_scan && h->slow_blob) {
           hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
-          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
-          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(SMX_SLOW_BLOCKS), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
         } else {
           hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
           hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
