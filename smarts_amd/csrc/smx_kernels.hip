@@ -1949,6 +1949,9 @@ __device__ __forceinline__ void waypoints_role(const KernelArgs& a, const int bl
 // their rows are skipped in step 3.
 // =================================================================================
 #define SMX_WPT_MAX_PATHS 8  // dense rows per vehicle (wp_paths) the staged form handles
+// floor(e / d) for 0 <= e < 4096, 1 <= d <= 64, rcp = 1.0f / d: (e + 0.5) / d is at least 0.5 / d away from an integer,
+// the float32 product is off by less than 4096 / d * 2^-22
+__device__ __forceinline__ int small_quotient(int e, float rcp) { return (int)(((float)e + 0.5f) * rcp); }
 #define SMX_WPT_VEHICLES (SMX_BLOCK / SMX_WP_LANES)
 enum { SMX_ROW_SKIP = -2, SMX_ROW_ZERO = -1 };
 
@@ -2556,6 +2559,8 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   __shared__ signed char hdr_li0[SMX_BLOCK];
   __shared__ unsigned char hdr_one_lane[SMX_BLOCK];
   __shared__ double first_wp[SMX_WPT_VEHICLES][3];
+  __shared__ unsigned char rows_live[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS], rows_zero[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];
+  static_assert(SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS <= 256, "row numbers are bytes");
   static_assert(sizeof(WpKnot) == 32 && sizeof(WpKnotLanes) == 4, "WpKnot layout");
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
@@ -2789,17 +2794,58 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   __syncthreads();
   SMX_TSTAMP(te3);
   SMX_TACC(34, te2, te3);
-  // ---- 3. the waypoint slots of the workgroup's vehicles in memory order, a lane per waypoint.  Four slots per lane
+  // ---- 3. the waypoint slots of the workgroup's rows, a lane per waypoint.  The rows that hold a path first, in memory
+  // order (a road of three lanes leaves every fourth row empty, and the slot arithmetic is straight-line code that a lane
+  // without a path went through all the same: a fifth round of four for nothing); then the empty rows, zeros only.
+  // Four slots per lane
   // and round, their arithmetic written without branches (every read at a clamped index, results selected at the end):
   // the four dependency chains — header, interval search, two knot records, three divisions, the heading wrap — are
   // independent, and straight-line code is what lets the compiler interleave them (a wavefront alone on its SIMD half
   // the time issues one chain's instruction every ten cycles or so).  Only the rare lane look-ups keep their branch.
+  int n_rows_live = 0, n_rows_zero = 0;  // (uniform: the workgroup is one wavefront)
   {
-    const int elems = SMX_WPT_VEHICLES * P * W;
-    int row = threadIdx.x / W, i = threadIdx.x - row * W;  // element e = row * W + i, advanced by 64 per slot
-    int vv = row / P, slot = row - vv * P;                 // row = vv * P + slot: team vv's path row `slot`
+    static_assert(SMX_BLOCK == 64, "one ballot per 64 rows");
+    const int n_rows = SMX_WPT_VEHICLES * P;
+    const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+    for (int r0 = 0; r0 < n_rows; r0 += SMX_BLOCK) {
+      const int r = r0 + (int)threadIdx.x;
+      const int src = r < n_rows ? (int)book.src[r] : (int)SMX_ROW_SKIP;
+      const unsigned long long ml = __ballot(src >= 0), mz = __ballot(src == SMX_ROW_ZERO);
+      if (src >= 0) rows_live[n_rows_live + __popcll(ml & below)] = (unsigned char)r;
+      if (src == SMX_ROW_ZERO) rows_zero[n_rows_zero + __popcll(mz & below)] = (unsigned char)r;
+      n_rows_live += __popcll(ml);
+      n_rows_zero += __popcll(mz);
+    }
+  }
+  __syncthreads();
+  {
+    const float rcp_p = 1.0f / (float)P;  // (row -> vehicle: small_quotient, rows below 128)
     const int drow = SMX_BLOCK / W, di = SMX_BLOCK - drow * W;
-    const int last_row = SMX_WPT_VEHICLES * P - 1;
+    {  // the empty rows of the workgroup's tabled vehicles: zeros, lane ids -1
+      int ridx = threadIdx.x / W, i = threadIdx.x - ridx * W;
+      for (int e = threadIdx.x; e < n_rows_zero * W; e += SMX_BLOCK) {
+        const int row = rows_zero[ridx];
+        const int vq = small_quotient(row, rcp_p);
+        const size_t q = ((size_t)book.veh[vq] * P + (row - vq * P)) * W + i;
+        double* dst = o.wp_pos + q * 3;
+        dst[0] = 0.0;
+        dst[1] = 0.0;
+        dst[2] = 0.0;
+        o.wp_heading[q] = 0.0f;
+        o.wp_lane_width[q] = 0.0f;
+        o.wp_speed_limit[q] = 0.0f;
+        o.wp_lane_id[q] = (int16_t)-1;
+        o.wp_lane_index[q] = (int8_t)0;
+        ridx += drow;
+        i += di;
+        if (i >= W) {
+          i -= W;
+          ++ridx;
+        }
+      }
+    }
+    const int elems = n_rows_live * W;
+    int ridx = threadIdx.x / W, i = threadIdx.x - ridx * W;  // element e = ridx * W + i, advanced by 64 per slot
     constexpr int U = 4;
     for (int e0 = threadIdx.x; e0 < (SMX_SKIP(a, 1 << 21) ? 0 : elems); e0 += U * SMX_BLOCK) {
       int s_row[U], s_i[U], s_vv[U], s_slot[U];
@@ -2807,21 +2853,15 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         s_in[u] = e0 + u * SMX_BLOCK < elems;
-        s_row[u] = min(row, last_row);
+        s_row[u] = rows_live[min(ridx, n_rows_live - 1)];
         s_i[u] = i;
-        s_vv[u] = min(vv, SMX_WPT_VEHICLES - 1);
-        s_slot[u] = min(slot, P - 1);
-        row += drow;
-        slot += drow;
+        s_vv[u] = small_quotient(s_row[u], rcp_p);
+        s_slot[u] = s_row[u] - s_vv[u] * P;
+        ridx += drow;
         i += di;
         if (i >= W) {
           i -= W;
-          ++row;
-          ++slot;
-        }
-        while (slot >= P) {
-          slot -= P;
-          ++vv;
+          ++ridx;
         }
       }
       SMX_TSTAMP(tr0);
@@ -3080,9 +3120,6 @@ __device__ __forceinline__ void zero_dense_rows(const KernelArgs& a, size_t gid,
 // vehicles are adjacent — so a store instruction writes consecutive elements instead of one element of 64 rows.
 // (Scalars per agent — done, active, reward, counts — are consecutive across lanes as they are.)
 #define SMX_NB_STAGE 16  // neighbour rows per agent the staged form handles (nb_max; StdObs keeps 10)
-// floor(e / d) for 0 <= e < 4096, 1 <= d <= 64, rcp = 1.0f / d: (e + 0.5) / d is at least 0.5 / d away from an integer,
-// the float32 product is off by less than 4096 / d * 2^-22
-__device__ __forceinline__ int small_quotient(int e, float rcp) { return (int)(((float)e + 0.5f) * rcp); }
 static_assert(SMX_BLOCK * SMX_NB_STAGE * 3 < 4096, "small_quotient's range");
 struct ObsStage {
   float ego_f32[SMX_BLOCK][SMX_EGO_F32_COUNT];
