@@ -3750,6 +3750,9 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_FAST_ON_JUNCTIONS  // developer: the one-lane kernels + slow lists on maps with junctions too
+#define SMX_FAST_ON_JUNCTIONS 0
+#endif
 #ifndef SMX_SIDE_PRIO  // developer: side streams that get the default priority instead of the lowest (bit i = side i)
 #define SMX_SIDE_PRIO 0
 #endif
@@ -4117,9 +4120,13 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_sensors(const KernelArgs a) {
 // auto-reset tick pays for one empty launch instead of three.  (OGM tiles need dynamic LDS and keep
 // their own launch.)
 // =================================================================================
-#define SMX_FIRST_BLOCK 256
+// (eight wavefronts: the (vehicle, scan half) pairs of a restarted 64-vehicle env are 128 teams of eight lanes — four
+// rounds of ~55 us each in a workgroup of 256, the largest piece of C5's reset pass; the waypoint teams, four lanes a
+// vehicle, fit the first 256 threads, whose knot scratch is all the LDS the workgroup may have)
+#define SMX_FIRST_BLOCK 512
+#define SMX_FIRST_WP_THREADS 256
 __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
-  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_FIRST_BLOCK];
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_FIRST_WP_THREADS];
   const smx_config& c = a.cfg;
   const MapDev& m = a.map;
   const int n_veh = c.num_vehicles;
@@ -4153,10 +4160,11 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
   __threadfence();
   __syncthreads();
   // ---- sensors
-  for (size_t base = g0; base < g1; base += SMX_FIRST_BLOCK / SMX_WP_LANES) {
-    const size_t gid = base + threadIdx.x / SMX_WP_LANES;
-    if (gid < g1) waypoints_for<SMX_FIRST_BLOCK>(a, gid, knot_scratch + threadIdx.x);
-  }
+  if (threadIdx.x < SMX_FIRST_WP_THREADS)  // (whole wavefronts; waypoints_for holds no barrier)
+    for (size_t base = g0; base < g1; base += SMX_FIRST_WP_THREADS / SMX_WP_LANES) {
+      const size_t gid = base + threadIdx.x / SMX_WP_LANES;
+      if (gid < g1) waypoints_for<SMX_FIRST_WP_THREADS>(a, gid, knot_scratch + threadIdx.x);
+    }
   observe_role(a, block);
   if ((c.sensors & SMX_SENSOR_LIDAR) && a.lidar_blocks != 0)  // (0: the reset pass launched k_lidar for the new vehicles)
     for (size_t gid = g0; gid < g1; ++gid) {
@@ -4488,6 +4496,7 @@ struct smx_handle_s {
   double heading_gain_pos, lateral_gain_pos;
   double nb_d2_max;
   int slow_blocks;  // grid of the slow lists' kernels (smx_load_map)
+  bool map_junctions;  // some lane of the map is junction-internal
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
   int launch_strategy;  // SMX_LAUNCH_*
@@ -4582,6 +4591,7 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->lateral_gain_pos = 3.4;
   h->nb_d2_max = radius_threshold(h->cfg.nb_radius);
   h->slow_blocks = SMX_SLOW_BLOCKS;
+  h->map_junctions = false;
   h->timing = false;
   h->ev_used = 0;
   h->phase_timing = false;
@@ -4724,6 +4734,7 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     for (size_t i = 0; i < nl && !junctions; ++i) junctions = t->lane_in_junction[i] != 0;
     const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
     const size_t teams_per_block = SMX_BLOCK / SMX_WP_LANES;
+    h->map_junctions = junctions;
     h->slow_blocks = SMX_SLOW_BLOCKS;
     if (junctions) h->slow_blocks = (int)std::min<size_t>(8192, std::max<size_t>(SMX_SLOW_BLOCKS, tv / (2 * teams_per_block)));
   }
@@ -5410,7 +5421,11 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
                        counters + (h->alive_parity ^ 1), slow_counters + 4 * (h->alive_parity ^ 1));
     a.alive_list = h->alive_blob;
     a.alive_count = counters + h->alive_parity;
-    fast_scan = true;
+    // One lane per vehicle + slow lists where the slow lists stay short: a map without junctions (loop: under 1 % of
+    // the vehicles).  Where lanes branch and cross, a third of the vehicles would take the lists' serial forms
+    // (minicity, 262 144 vehicles: 1.40 ms a tick against 0.9x with round 2's team kernels for everybody), so those
+    // maps keep the team kernels.
+    fast_scan = !h->map_junctions || SMX_FAST_ON_JUNCTIONS;
     slow_parity = h->alive_parity;
     h->alive_parity ^= 1;
   }
@@ -5509,7 +5524,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       r.lidar_blocks = 0;
     }
     // large batches: k_first also walks the new vehicles' knot lists, for the next tick's k_control_fast
-    r.walk_new = (!small_batch && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) && c.wp_paths <= SMX_WPT_MAX_PATHS) ? 1 : 0;
+    // (only k_control_fast reads them: not on the maps that keep the team kernels)
+    r.walk_new = (!small_batch && (!h->map_junctions || SMX_FAST_ON_JUNCTIONS) && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) &&
+                  c.wp_paths <= SMX_WPT_MAX_PATHS) ? 1 : 0;
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }
   SMX_HIP(hipGetLastError());

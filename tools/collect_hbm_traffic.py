@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--write", required=True)
     ap.add_argument("--workload-key", required=True)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--bench-json", default=None,
+                    help="stdout of the profiled bench.py command (its JSON line): the alive agents per tick of that run are kept in the record")
     args = ap.parse_args()
     fetch, fd = read_counters(args.fetch, "FETCH_SIZE")
     write, wd = read_counters(args.write, "WRITE_SIZE")
@@ -81,6 +83,17 @@ def main():
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (upper bound: the doubling is calibrated for wide "
                   "coalesced reads only)",
     }
+    if args.bench_json:
+        # the counters are those of the agents alive in the profiled ticks (an agent that is gone writes no rows)
+        line = json.loads(open(args.bench_json).read().strip().splitlines()[-1])
+        alive = line["config"]["alive_agents_per_tick"]
+        rec["alive_agents_per_tick"] = alive["mean_rank0"]
+        rec["agent_slots"] = alive["of"]
+        rec["alive_fraction"] = alive["mean_rank0"] / alive["of"]
+        rec["bytes_per_alive_agent_step"] = rec["bytes_per_step"] / alive["mean_rank0"]
+        rec["algorithmic_bytes_per_step"] = line["roofline"]["algorithmic_bytes"]["total"]
+        rec["profiled_command"] = "bench.py steps %d warmup %d (this run: %.4f ms per tick under the counters)" % (
+            line["steps"], line["warmup"], line["ms_per_step"])
     with open(args.out, "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps({k: rec[k] for k in ("read_bytes_per_step", "write_bytes_per_step", "bytes_per_step")}))
