@@ -4496,7 +4496,7 @@ struct smx_handle_s {
   double heading_gain_pos, lateral_gain_pos;
   double nb_d2_max;
   int slow_blocks;  // grid of the slow lists' kernels (smx_load_map)
-  bool map_junctions;  // some lane of the map is junction-internal
+  bool map_junctions;  // lanes of the map split (some lanepoint has several successors)
   double dagm_reach;  // half the widest lane width of the loaded map
   int debug_skip;
   int launch_strategy;  // SMX_LAUNCH_*
@@ -4725,13 +4725,15 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
   h->dagm_reach = 0.0;
   for (size_t i = 0; i < nl; ++i) h->dagm_reach = std::max(h->dagm_reach, 0.5 * t->lane_width[i]);
   // The slow lists' kernels run a fixed grid that strides a list whose length only the device knows.  On a map
-  // without junctions the lists hold a few vehicles of a hundred thousand and the grid is an empty launch's latency;
+  // whose lanes never split the lists hold a few vehicles of a hundred thousand and the grid is an empty launch's latency;
   // where lanes branch or cross, a third of the vehicles is on them (minicity, 262 144 vehicles: 77 000 rows through
   // 512 workgroups were half a wavefront per SIMD for nine passes, 1.4 ms of a 2.8 ms tick) — a team slot for every
   // second vehicle then.
   {
+    // (a lanepoint with several successors: lanes that split.  Junction-internal lanes alone do not tell — the loop map's
+    // two edges are joined by six of them, one successor each)
     bool junctions = false;
-    for (size_t i = 0; i < nl && !junctions; ++i) junctions = t->lane_in_junction[i] != 0;
+    for (int i = 0; i < t->n_lanepoints && !junctions; ++i) junctions = t->lp_rec[i].n_next > 1;
     const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
     const size_t teams_per_block = SMX_BLOCK / SMX_WP_LANES;
     h->map_junctions = junctions;
@@ -5421,8 +5423,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
                        counters + (h->alive_parity ^ 1), slow_counters + 4 * (h->alive_parity ^ 1));
     a.alive_list = h->alive_blob;
     a.alive_count = counters + h->alive_parity;
-    // One lane per vehicle + slow lists where the slow lists stay short: a map without junctions (loop: under 1 % of
-    // the vehicles).  Where lanes branch and cross, a third of the vehicles would take the lists' serial forms
+    // One lane per vehicle + slow lists where the slow lists stay short: a map whose lanes never split (loop: under 1 %
+    // of the vehicles).  Where lanes branch and cross, a third of the vehicles would take the lists' serial forms
     // (minicity, 262 144 vehicles: 1.40 ms a tick against 0.9x with round 2's team kernels for everybody), so those
     // maps keep the team kernels.
     fast_scan = !h->map_junctions || SMX_FAST_ON_JUNCTIONS;
