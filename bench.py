@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--vehicles", type=int, default=None)
     ap.add_argument("--scenario", default=None)
     ap.add_argument("--phase-steps", type=int, default=100)
-    ap.add_argument("--launch-strategy", default="auto", choices=("auto", "small", "large"),
+    ap.add_argument("--launch-strategy", default="auto", choices=("auto", "small", "large", "large_one_lane"),
                     help="how a tick is cut into launches (include/smx.h); auto = by vehicle count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -413,6 +413,7 @@ def main():
                                           "note": "an env restarts when all its agents are done; until then the "
                                                   "agents already done have no vehicle: rows and byte counts "
                                                   "are those of the alive agents"},
+                "launch_form": sim.launch_form(),
                 "sharding": f"{world} rank(s), envs [g*{total_envs}/{world}, (g+1)*{total_envs}/{world}) on GPU g "
                             f"({E} on rank 0); no data-path collective; per-tick reward/done all_gather (RCCL)",
                 "obs_build_ms_per_tick": obs_build_ms,

@@ -138,9 +138,10 @@ def bind_buffer(struct, names, name, tensor):
 EXPORTS = [
     "smx_create", "smx_load_map", "smx_set_vias", "smx_set_missions", "smx_step_continuous", "smx_step_trajectory", "smx_read_phase_ms", "smx_set_lidar_rays", "smx_reset", "smx_step", "smx_sync", "smx_last_step_ms",
     "smx_set_timing", "smx_last_error", "smx_version", "smx_destroy", "smx_set_controller_gains", "smx_struct_size", "smx_read_step_ms",
-    "smx_check_buffers", "smx_set_launch_strategy",
+    "smx_check_buffers", "smx_set_launch_strategy", "smx_launch_form",
 ]
-LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2}
+LAUNCH_FORMS = {0: "small", 1: "large_teams", 2: "large_one_lane"}
+LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2, "large_one_lane": 3}
 LARGE_BATCH_VEHICLES = 16384  # SMX_LAUNCH_AUTO: the LARGE form above this many vehicles (smx_kernels.hip)
 
 _lib: Optional[C.CDLL] = None
@@ -213,6 +214,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.smx_check_buffers.restype = C.c_int
     lib.smx_set_launch_strategy.argtypes = [h, C.c_int]
     lib.smx_set_launch_strategy.restype = C.c_int
+    lib.smx_launch_form.argtypes = [h]
+    lib.smx_launch_form.restype = C.c_int
     lib.smx_struct_size.argtypes = [C.c_int]
     lib.smx_struct_size.restype = C.c_uint64
     for which, mirror in enumerate((SmxConfig, SmxMapTables, SmxState, SmxSpawns, SmxOutputs)):

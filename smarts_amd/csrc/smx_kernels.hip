@@ -3750,9 +3750,6 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
-#ifndef SMX_FAST_ON_JUNCTIONS  // developer: the one-lane kernels + slow lists on maps with junctions too
-#define SMX_FAST_ON_JUNCTIONS 0
-#endif
 #ifndef SMX_SIDE_PRIO  // developer: side streams that get the default priority instead of the lowest (bit i = side i)
 #define SMX_SIDE_PRIO 0
 #endif
@@ -4667,9 +4664,19 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
 
 extern "C" int smx_set_launch_strategy(smx_handle h, int strategy) {
   if (!h) return SMX_ERR_INVALID;
-  if (strategy < SMX_LAUNCH_AUTO || strategy > SMX_LAUNCH_LARGE) return fail(h, SMX_ERR_INVALID, "unknown launch strategy");
+  if (strategy < SMX_LAUNCH_AUTO || strategy > SMX_LAUNCH_LARGE_ONE_LANE) return fail(h, SMX_ERR_INVALID, "unknown launch strategy");
   h->launch_strategy = strategy;
   return SMX_OK;
+}
+
+extern "C" int smx_launch_form(smx_handle h) {
+  if (!h) return SMX_ERR_INVALID;
+  if (!h->map_loaded) return fail(h, SMX_ERR_STATE, "smx_launch_form needs the map (the form depends on it)");
+  const size_t total = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+  const bool small_batch = h->launch_strategy == SMX_LAUNCH_SMALL ||
+                           (h->launch_strategy == SMX_LAUNCH_AUTO && total <= SMX_LARGE_BATCH_VEHICLES);
+  if (small_batch) return SMX_FORM_SMALL;
+  return (h->alive_blob && h->slow_blob && (!h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE)) ? SMX_FORM_LARGE_ONE_LANE : SMX_FORM_LARGE_TEAMS;
 }
 
 extern "C" int smx_set_controller_gains(smx_handle h, double heading_gain, double lateral_gain) {
@@ -5427,7 +5434,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     // of the vehicles).  Where lanes branch and cross, a third of the vehicles would take the lists' serial forms
     // (minicity, 262 144 vehicles: 1.40 ms a tick against 0.9x with round 2's team kernels for everybody), so those
     // maps keep the team kernels.
-    fast_scan = !h->map_junctions || SMX_FAST_ON_JUNCTIONS;
+    fast_scan = !h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE;
     slow_parity = h->alive_parity;
     h->alive_parity ^= 1;
   }
@@ -5527,7 +5534,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     }
     // large batches: k_first also walks the new vehicles' knot lists, for the next tick's k_control_fast
     // (only k_control_fast reads them: not on the maps that keep the team kernels)
-    r.walk_new = (!small_batch && (!h->map_junctions || SMX_FAST_ON_JUNCTIONS) && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) &&
+    r.walk_new = (!small_batch && (!h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) &&
                   c.wp_paths <= SMX_WPT_MAX_PATHS) ? 1 : 0;
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }

@@ -461,7 +461,14 @@ class BatchedSim:
     def small_form(self) -> bool:
         """Whether a tick runs in the SMALL launch form (smx_kernels.hip: SMX_LARGE_BATCH_VEHICLES)."""
         s = self.cfg.launch_strategy
-        return s == "small" or (s == "auto" and self.E * self.N <= nat.LARGE_BATCH_VEHICLES)
+        return s == "small" or (s == "auto" and self.E * self.N <= nat.LARGE_BATCH_VEHICLES)  # ("large*": never)
+
+    def launch_form(self) -> str:
+        """The form the library runs a tick in: "small", "large_teams" or "large_one_lane" (smx_launch_form)."""
+        rc = self.lib.smx_launch_form(self.handle)
+        if rc < 0:
+            nat.check(self.lib, self.handle, rc, "smx_launch_form")
+        return nat.LAUNCH_FORMS[rc]
 
     def handoff_bytes_per_agent_step(self) -> int:
         """Bytes written by one kernel of the tick and read by a later one (path seeds, road facts, next flags):

@@ -43,7 +43,11 @@ def _make(name, E, N, nets, compiled_maps, seed, **cfg_kw):
     ("loop", 3, 8, 30, 116, dict(wp_paths=2, wp_len=33)),   # rows of the whole lookahead, fewer rows than lanes
     ("4lane", 2, 8, 20, 117, dict(wp_paths=8, wp_len=10)),  # more rows than a road has lanes
 ])
-def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, extra, nets, compiled_maps):
+@pytest.mark.parametrize("cut", ["large", "large_one_lane"])
+def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, extra, cut, nets, compiled_maps):
+    """Both cuts of the LARGE form on every map: "large" picks by the map (teams where lanes split, one lane per
+    vehicle + slow lists on loop), "large_one_lane" forces the latter — on 4lane / minicity a third of the vehicles
+    then goes through the slow lists (branchings, junction roads, new roads)."""
     import torch
 
     from smarts_amd.lidar import Planar100
@@ -51,7 +55,10 @@ def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, e
     extra = dict(extra)
     if extra.get("lidar") == "planar100":
         extra["lidar"] = Planar100
-    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, launch_strategy="large", **extra)
+    if cut == "large_one_lane" and name == "loop":
+        pytest.skip("loop's lanes never split: \"large\" is the one-lane cut there")
+    sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, launch_strategy=cut, **extra)
+    assert sim.launch_form() == ("large_one_lane" if (cut == "large_one_lane" or name == "loop") else "large_teams")
     d, o = _host(sim.reset()), ob.reset_observe()
     assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
     rng = np.random.default_rng(seed)
@@ -72,7 +79,7 @@ def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, e
     ("loop", 32, dict(ogm=True, ogm_width=64, ogm_height=64, ogm_resolution=50 / 64)),
 ])
 def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
-    """SMALL and LARGE run the same role functions over different launches: 40 auto-reset ticks of the same
+    """SMALL and both cuts of LARGE run the same arithmetic over different launches: 40 auto-reset ticks of the same
     batch must leave identical bits in every output and in the whole state."""
     import torch
 
@@ -86,7 +93,8 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
     E = max(2, 192 // N)
     spawns = make_spawns(cm, E, N, episodes=3, seed=21)
     sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
-                                     launch_strategy=s, **extra), spawns=spawns) for s in ("small", "large")]
+                                     launch_strategy=s, **extra), spawns=spawns) for s in ("small", "large", "large_one_lane")]
+    assert [s.launch_form() for s in sims] == ["small", "large_one_lane" if name == "loop" else "large_teams", "large_one_lane"]
     rng = np.random.default_rng(21)
     for s in sims:
         s.reset()
@@ -95,10 +103,11 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
         outs = [s.step(acts) for s in sims]
         if t % 13 == 0 or t == 39:
             torch.cuda.synchronize()
-            for k in outs[0]:
-                assert np.array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), equal_nan=True), (t, k)
-            assert np.array_equal(sims[0].state.cpu().numpy(), sims[1].state.cpu().numpy(), equal_nan=True), t
-            assert np.array_equal(sims[0].flags.cpu().numpy(), sims[1].flags.cpu().numpy()), t
+            for other in (1, 2):
+                for k in outs[0]:
+                    assert np.array_equal(outs[0][k].cpu().numpy(), outs[other][k].cpu().numpy(), equal_nan=True), (t, k, other)
+                assert np.array_equal(sims[0].state.cpu().numpy(), sims[other].state.cpu().numpy(), equal_nan=True), (t, other)
+                assert np.array_equal(sims[0].flags.cpu().numpy(), sims[other].flags.cpu().numpy()), (t, other)
     for s in sims:
         s.close()
 

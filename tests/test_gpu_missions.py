@@ -27,7 +27,7 @@ def _golden_routes(g):
     return [[str(r) for r in g["route_roads"][off[k]:off[k + 1]]] for k in range(int(g["n_routes"]))]
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("strategy", ["small", "large", "large_one_lane"])
 @pytest.mark.parametrize("name", MAP_NAMES)
 def test_routed_rows_and_route_events_equal_the_reference(name, strategy, compiled_maps):
     import torch
@@ -54,7 +54,7 @@ def test_routed_rows_and_route_events_equal_the_reference(name, strategy, compil
         # goal far from every pose: reached_goal stays off
         sim.set_missions([PlannedMission((0.0, 0.0), 0.0, (1e7, 1e7, 1.0), tuple(roads))])
         out = sim.reset()
-        if strategy == "large":
+        if strategy.startswith("large"):
             out = sim.step(torch.full((len(rows), 1), -1, dtype=torch.int8, device="cuda"))
         ev = _host(out["events"])[:, 0]
         differing += [int(rows[i]) for i in differing_waypoint_rows(out, w, lane_no, P, W)]
@@ -80,7 +80,7 @@ def _missions_4lane(nets):
     return [plan_mission(net, Mission(r)) for r in specs]
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("strategy", ["small", "large", "large_one_lane"])
 @pytest.mark.parametrize("waypoints", [True, False])
 def test_fixed_route_rollout_against_the_oracle(strategy, waypoints, nets, compiled_maps):
     """Four agents drive their planned missions on the 4lane junction (one of them steered off its route by lane
@@ -217,7 +217,7 @@ def test_hiway_env_mission_ends_at_its_goal():
     env.close()
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("strategy", ["small", "large", "large_one_lane"])
 def test_fixed_route_rollout_on_minicity(strategy, nets, compiled_maps):
     """Routes of the reference-generated fixture (several junctions each) driven on the big map: every output of
     every tick against the oracle, teacher-forced; one agent of three keeps an endless mission."""
