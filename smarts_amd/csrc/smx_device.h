@@ -44,6 +44,8 @@ __device__ unsigned long long smx_prof[128];
 //  stamps then measure themselves; slot + 64 counts the reports)
 #define SMX_TACC(slot, t0, t1) \
   do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&smx_prof[slot], (t1) - (t0)); atomicAdd(&smx_prof[(slot) + 64], 1ull); } } while (0)
+#define SMX_TACC_ALL(slot, t0, t1) \
+  do { if (threadIdx.x == 0) { atomicAdd(&smx_prof[slot], (t1) - (t0)); atomicAdd(&smx_prof[(slot) + 64], 1ull); } } while (0)
 #define SMX_COUNT(slot, cond) \
   do { if (cond) atomicAdd(&smx_prof[slot], 1ull); } while (0)
 // a wavefront's whole span in a kernel, every wavefront its own word (no atomics: 8 192 of them on one address take
@@ -59,6 +61,7 @@ __device__ unsigned int smx_span[SMX_SPAN_KERNELS * SMX_SPAN_WAVES];
 #else
 #define SMX_TSTAMP(var)
 #define SMX_TACC(slot, t0, t1)
+#define SMX_TACC_ALL(slot, t0, t1)
 #define SMX_COUNT(slot, cond)
 #define SMX_TSPAN(slot, t0, t1)
 #endif

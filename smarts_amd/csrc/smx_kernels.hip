@@ -4138,6 +4138,7 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
     mine_first = (f & SMX_F_ALIVE) && (f & SMX_F_FIRST);
   }
   if (!__syncthreads_or(mine_first)) return;
+  SMX_TSTAMP(tk0);
   // The workgroup is four wavefronts wide: a restarted env's chain scan -> sensors -> commit is
   // pure latency, so its independent pieces run side by side — (vehicle, scan half) pairs over the
   // teams of all four wavefronts, then the vehicles' waypoint teams — instead of one after the
@@ -4156,13 +4157,19 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
   }
   __threadfence();
   __syncthreads();
+  SMX_TSTAMP(tk1);
+  SMX_TACC_ALL(57, tk0, tk1);
   // ---- sensors
   if (threadIdx.x < SMX_FIRST_WP_THREADS)  // (whole wavefronts; waypoints_for holds no barrier)
     for (size_t base = g0; base < g1; base += SMX_FIRST_WP_THREADS / SMX_WP_LANES) {
       const size_t gid = base + threadIdx.x / SMX_WP_LANES;
       if (gid < g1) waypoints_for<SMX_FIRST_WP_THREADS>(a, gid, knot_scratch + threadIdx.x);
     }
+  SMX_TSTAMP(tk2);
+  SMX_TACC_ALL(58, tk1, tk2);
   observe_role(a, block);
+  SMX_TSTAMP(tk3);
+  SMX_TACC_ALL(59, tk2, tk3);
   if ((c.sensors & SMX_SENSOR_LIDAR) && a.lidar_blocks != 0)  // (0: the reset pass launched k_lidar for the new vehicles)
     for (size_t gid = g0; gid < g1; ++gid) {
       lidar_role(a, (int)gid);
@@ -4171,7 +4178,11 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
   __threadfence();
   __syncthreads();
   // ---- commit
+  SMX_TSTAMP(tk4);
   commit_role(a, block);
+  SMX_TSTAMP(tk5);
+  SMX_TACC_ALL(60, tk4, tk5);
+  SMX_TACC_ALL(61, tk0, tk5);
   // ---- large batches: the new vehicles' knot lists, so that the next tick's k_control_fast serves them too (a new
   // vehicle without lists went through the slow controller, two launches of pure latency in front of everything else
   // of the tick).  New here: alive, SMX_F_FIRST just cleared by the commit, one step old.
