@@ -1610,16 +1610,18 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_scan_fast(const KernelArgs a) {
 }
 
 // k_scan_half over a list whose length is only known on the device (the slow list): a fixed grid, teams striding it
-template <int ROLE, bool ROUTED = false>
+// (TEAM: four lanes a vehicle where the lists are long — maps whose lanes split —, eight where they hold a few
+// hundred vehicles and the kernel is one team's latency at the end of the slow chain: 70 against 55 us)
+template <int ROLE, bool ROUTED = false, int TEAM = SMX_TEAM_LARGE>
 __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_listed(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
   const int count = *a.slow_count;
-  constexpr int VPB = SMX_BLOCK / SMX_TEAM_LARGE;
-  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_TEAM_LARGE; i < count; i += (int)gridDim.x * VPB) {
+  constexpr int VPB = SMX_BLOCK / TEAM;
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / TEAM; i < count; i += (int)gridDim.x * VPB) {
     const size_t gid = (size_t)a.slow_list[i];
     const int flags = a.st.flags[gid];
-    scan_role<SMX_TEAM_LARGE, ROUTED>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
+    scan_role<TEAM, ROUTED>(a, a.map, c, gid, total, team_rank<TEAM>(), flags, ROLE);
   }
 }
 
@@ -4375,6 +4377,21 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_listed(const KernelArgs
   for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
     waypoints_for<SMX_BLOCK>(a, (size_t)a.slow_list[i], knot_scratch + threadIdx.x);
 }
+// the slow chain's form (short lists: its latency ends the chain): eight lanes a vehicle — four emit the rows
+// (waypoints_for), four walk the knot lists for the next tick's controller (k_wp_walk_listed's work) beside them
+__global__ void __launch_bounds__(SMX_BLOCK) k_waypoints_walk_listed(const KernelArgs a) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
+  const int count = *a.slow_count;
+  constexpr int VPB = SMX_BLOCK / (2 * SMX_WP_LANES);
+  const bool walker = ((threadIdx.x / SMX_WP_LANES) & 1) != 0;  // (uniform in an aligned group of four lanes)
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / (2 * SMX_WP_LANES); i < count; i += (int)gridDim.x * VPB) {
+    const size_t gid = (size_t)a.slow_list[i];
+    if (walker)
+      wp_walk_for(a, gid, (int)threadIdx.x % SMX_WP_LANES, false);
+    else
+      waypoints_for<SMX_BLOCK>(a, gid, knot_scratch + threadIdx.x);
+  }
+}
 // (capped at 168 registers for a third wavefront per SIMD beside the waypoint kernels it spills 52 of them: 0.796 -> 0.806 ms)
 __global__ void __launch_bounds__(SMX_BLOCK) k_observe(const KernelArgs a) {
   SMX_TSTAMP(span0);
@@ -5335,9 +5352,16 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
           (void)hipEventRecord(h->ev_fork, stream);
           seeds_fork_recorded = true;
           (void)hipStreamWaitEvent(h->side[2], h->ev_fork, 0);
-          hipLaunchKernelGGL(k_scan_listed<1>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
-          hipLaunchKernelGGL(k_waypoints_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
-          if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          if (h->map_junctions)
+            hipLaunchKernelGGL(k_scan_listed<1>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          else
+            hipLaunchKernelGGL((k_scan_listed<1, false, SMX_TEAM>), dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          if (!h->map_junctions && h->knots_blob) {
+            hipLaunchKernelGGL(k_waypoints_walk_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          } else {
+            hipLaunchKernelGGL(k_waypoints_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+            if (h->knots_blob) hipLaunchKernelGGL(k_wp_walk_listed, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, h->side[2], ks);
+          }
           slow_chain_forked = true;
         } else {
           slow_chain_pending = true;  // (one stream: after the main waypoint kernels, below)
