@@ -142,6 +142,7 @@ EXPORTS = [
 ]
 LAUNCH_FORMS = {0: "small", 1: "large_teams", 2: "large_one_lane"}
 LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2, "large_one_lane": 3}
+OGM_ENV_MIN_VEHICLES = 8192  # small form: OGM tiles by k_ogm_env from this many vehicles on (SMX_OGM_ENV_MIN_VEHICLES)
 LARGE_BATCH_VEHICLES = 16384  # SMX_LAUNCH_AUTO: the LARGE form above this many vehicles (smx_kernels.hip)
 
 _lib: Optional[C.CDLL] = None

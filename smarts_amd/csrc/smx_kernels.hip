@@ -3752,6 +3752,9 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_OGM_ENV_MIN_VEHICLES  // small form: OGM tiles by k_ogm_env from this many vehicles on (smarts_amd/engine.py mirrors it)
+#define SMX_OGM_ENV_MIN_VEHICLES 8192
+#endif
 #ifndef SMX_SIDE_PRIO  // developer: side streams that get the default priority instead of the lowest (bit i = side i)
 #define SMX_SIDE_PRIO 0
 #endif
@@ -5282,7 +5285,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // the OGM tile is dynamic LDS: on small batches, up to 16 KiB, it rides along in k_sensors; otherwise
   // the OGM role gets its own launch
   const size_t ogm_bytes = (c.sensors & SMX_SENSOR_OGM) ? (size_t)c.ogm_width * c.ogm_height : 0;
-  const bool ogm_inline = small_batch && ogm_bytes > 0 && ogm_bytes <= 16 * 1024;
+  // (from SMX_OGM_ENV_MIN_VEHICLES on, the per-env kernel of the large form beats the per-observer role inside
+  // k_sensors even as a launch of its own on the same stream: a third of the instructions per tile)
+  const bool ogm_env_small = small_batch && total >= SMX_OGM_ENV_MIN_VEHICLES && c.num_vehicles <= 32 && ogm_bytes * SMX_OGM_WAVES * 2 <= 64 * 1024;
+  const bool ogm_inline = small_batch && ogm_bytes > 0 && ogm_bytes <= 16 * 1024 && !ogm_env_small;
   const bool ogm_alone = ogm_bytes > 0 && !ogm_inline;
   const size_t dagm_bytes = (c.sensors & SMX_SENSOR_DAGM) ? (size_t)c.dagm_width * c.dagm_height : 0;
   a.dagm_reach = h->dagm_reach;
@@ -5295,7 +5301,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   // OGM tiles on their own: per env (four wavefronts share the env's poses) on large batches while four
   // tiles fit a workgroup's LDS, else per observer
   auto launch_ogm = [&](hipStream_t st_, const KernelArgs& k) {
-    if (!small_batch && c.num_vehicles <= 32 && ogm_bytes * SMX_OGM_WAVES * 2 <= 64 * 1024)
+    if ((!small_batch || ogm_env_small) && c.num_vehicles <= 32 && ogm_bytes * SMX_OGM_WAVES * 2 <= 64 * 1024)
       hipLaunchKernelGGL(k_ogm_env<2>, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES * 2, st_, k);
     else if (!small_batch && ogm_bytes * SMX_OGM_WAVES <= 64 * 1024)
       hipLaunchKernelGGL(k_ogm_env<1>, dim3((unsigned)c.num_envs), dim3(SMX_OGM_WAVES * 64), ogm_bytes * SMX_OGM_WAVES, st_, k);

@@ -424,8 +424,11 @@ class BatchedSim:
         }
         ogm = (pose, o["ogm"]) if self.cfg.ogm else (0, 0)
         dagm = (pose, o["dagm"]) if self.cfg.dagm else (0, 0)
-        ogm_inline = (self.cfg.ogm and self.cfg.ogm_width * self.cfg.ogm_height <= 16 * 1024
-                      and self.small_form())  # smx_kernels.hip enqueue(): small batches only
+        tile = self.cfg.ogm_width * self.cfg.ogm_height
+        ogm_env_small = (self.small_form() and self.E * self.N >= nat.OGM_ENV_MIN_VEHICLES and self.N <= 32
+                         and tile * 8 <= 64 * 1024)  # smx_kernels.hip enqueue(): k_ogm_env on small batches too
+        ogm_inline = (self.cfg.ogm and tile <= 16 * 1024
+                      and self.small_form() and not ogm_env_small)  # smx_kernels.hip enqueue(): small batches only
         add = lambda a, b: (a[0] + b[0], a[1] + b[1])  # noqa: E731
         if (self.cfg.ogm and not ogm_inline) or self.cfg.dagm:
             kb["ogm"] = add((0, 0) if ogm_inline else ogm, dagm)  # their own launches (one timing phase)

@@ -26,7 +26,7 @@ bench)
   for c in c2 c3 c5; do python bench.py --config $c --no-cpu-baseline > $OUT/${R}_bench_$c.json 2> $OUT/bench_$c.err; echo "bench $c rc=$?"; done
   for E in 512 1024 2048; do python bench.py --envs-per-gpu $E --no-cpu-baseline --phase-steps 0 > $OUT/${R}_bench_c4_shard_$E.json 2> $OUT/bench_shard_$E.err; echo "shard $E rc=$?"; done ;;
 stats)
-  for c in c4 c3 c5; do
+  for c in ${STATS_CONFIGS:-c4 c3 c5}; do
     rm -rf $OUT/prof_final $OUT/prof_serial
     (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_final -o runc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu-baseline --phase-steps 0 > $OUT/prof_bench_$c.json 2> $OUT/prof_bench_$c.err); echo "rocprof $c rc=$?"
     cp $(find $OUT/prof_final -name "*kernel_stats.csv" | head -1) $OUT/${R}_kernel_stats_$c.csv
