@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--vehicles", type=int, default=None)
     ap.add_argument("--scenario", default=None)
     ap.add_argument("--phase-steps", type=int, default=100)
-    ap.add_argument("--launch-strategy", default="auto", choices=("auto", "small", "large", "large_one_lane"),
+    ap.add_argument("--launch-strategy", default="auto", choices=("auto", "small", "large", "large_one_lane", "large_teams"),
                     help="how a tick is cut into launches (include/smx.h); auto = by vehicle count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)

@@ -141,7 +141,7 @@ EXPORTS = [
     "smx_check_buffers", "smx_set_launch_strategy", "smx_launch_form",
 ]
 LAUNCH_FORMS = {0: "small", 1: "large_teams", 2: "large_one_lane"}
-LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2, "large_one_lane": 3}
+LAUNCH_STRATEGIES = {"auto": 0, "small": 1, "large": 2, "large_one_lane": 3, "large_teams": 4}
 OGM_ENV_MIN_VEHICLES = 8192  # small form: OGM tiles by k_ogm_env from this many vehicles on (SMX_OGM_ENV_MIN_VEHICLES)
 LARGE_BATCH_VEHICLES = 16384  # SMX_LAUNCH_AUTO: the LARGE form above this many vehicles (smx_kernels.hip)
 

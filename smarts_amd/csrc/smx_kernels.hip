@@ -3752,6 +3752,9 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_ONE_LANE_MIN_VEHICLES  // LARGE picks the one-lane cut from this many vehicles on (on a map whose lanes never split)
+#define SMX_ONE_LANE_MIN_VEHICLES 65536
+#endif
 #ifndef SMX_OGM_ENV_MIN_VEHICLES  // small form: OGM tiles by k_ogm_env from this many vehicles on (smarts_amd/engine.py mirrors it)
 #define SMX_OGM_ENV_MIN_VEHICLES 8192
 #endif
@@ -4695,9 +4698,21 @@ extern "C" int smx_create(const smx_config* cfg, int device, smx_handle* out) {
 
 extern "C" int smx_set_launch_strategy(smx_handle h, int strategy) {
   if (!h) return SMX_ERR_INVALID;
-  if (strategy < SMX_LAUNCH_AUTO || strategy > SMX_LAUNCH_LARGE_ONE_LANE) return fail(h, SMX_ERR_INVALID, "unknown launch strategy");
+  if (strategy < SMX_LAUNCH_AUTO || strategy > SMX_LAUNCH_LARGE_TEAMS) return fail(h, SMX_ERR_INVALID, "unknown launch strategy");
   h->launch_strategy = strategy;
   return SMX_OK;
+}
+
+// Which cut of the LARGE form a batch takes (smx.h, smx_launch_form): one lane per vehicle + slow lists where the lists
+// stay short (a map whose lanes never split) AND the batch is big enough for throughput to decide — below
+// SMX_ONE_LANE_MIN_VEHICLES the tick is a chain of single-wavefront latencies either way, and the team kernels' chain
+// is the shorter one (C4's 1024-env shard over a long run: 0.229 against 0.266 ms; 2048 envs: 0.274 against 0.289, but
+// 0.435 against 0.392 with nine agents in ten alive; 3072: 0.368 against 0.321); the strategies LARGE_ONE_LANE / LARGE_TEAMS force a cut.
+static bool one_lane_cut(const smx_handle_s* h) {
+  if (h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) return true;
+  if (h->launch_strategy == SMX_LAUNCH_LARGE_TEAMS) return false;
+  const size_t total = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+  return !h->map_junctions && total >= SMX_ONE_LANE_MIN_VEHICLES;
 }
 
 extern "C" int smx_launch_form(smx_handle h) {
@@ -4707,7 +4722,7 @@ extern "C" int smx_launch_form(smx_handle h) {
   const bool small_batch = h->launch_strategy == SMX_LAUNCH_SMALL ||
                            (h->launch_strategy == SMX_LAUNCH_AUTO && total <= SMX_LARGE_BATCH_VEHICLES);
   if (small_batch) return SMX_FORM_SMALL;
-  return (h->alive_blob && h->slow_blob && (!h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE)) ? SMX_FORM_LARGE_ONE_LANE : SMX_FORM_LARGE_TEAMS;
+  return (h->alive_blob && h->slow_blob && one_lane_cut(h)) ? SMX_FORM_LARGE_ONE_LANE : SMX_FORM_LARGE_TEAMS;
 }
 
 extern "C" int smx_set_controller_gains(smx_handle h, double heading_gain, double lateral_gain) {
@@ -5475,7 +5490,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     // of the vehicles).  Where lanes branch and cross, a third of the vehicles would take the lists' serial forms
     // (minicity, 262 144 vehicles: 1.40 ms a tick against 0.9x with round 2's team kernels for everybody), so those
     // maps keep the team kernels.
-    fast_scan = !h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE;
+    fast_scan = one_lane_cut(h);
     slow_parity = h->alive_parity;
     h->alive_parity ^= 1;
   }
@@ -5575,7 +5590,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
     }
     // large batches: k_first also walks the new vehicles' knot lists, for the next tick's k_control_fast
     // (only k_control_fast reads them: not on the maps that keep the team kernels)
-    r.walk_new = (!small_batch && (!h->map_junctions || h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) &&
+    r.walk_new = (!small_batch && one_lane_cut(h) && h->knots_blob && (c.sensors & SMX_SENSOR_WAYPOINTS) &&
                   c.wp_paths <= SMX_WPT_MAX_PATHS) ? 1 : 0;
     hipLaunchKernelGGL(k_first, dim3(obs_blocks), dim3(SMX_FIRST_BLOCK), 0, stream, r);
   }

@@ -77,7 +77,7 @@ def differing_waypoint_rows(out, w, lane_no, P, W):
     return differing
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("strategy", ["small", "large", "large_one_lane"])
 @pytest.mark.parametrize("name", MAP_NAMES)
 def test_waypoint_rows_equal_the_reference(name, strategy, compiled_maps):
     cm = compiled_maps(name)
@@ -86,7 +86,7 @@ def test_waypoint_rows_equal_the_reference(name, strategy, compiled_maps):
     P, W = 8, 33  # every waypoint of every path the rows can hold
     sim = _sim_at_poses(cm, w["poses"], wp_paths=P, wp_len=W, wp_lookahead=32, launch_strategy=strategy)
     out = sim.reset()
-    if strategy == "large":
+    if strategy.startswith("large"):
         # the reset pass is one form for every batch; the large form's waypoint kernels run in a tick: stand still
         # (zero speed, no action moves a stationary sedan's centre) and read the tick's rows
         import torch
@@ -121,7 +121,7 @@ def test_nearest_lane_and_off_road_equal_the_reference(name, compiled_maps):
 LANE_ACTION = {(15.0, 0): 0, (0.0, 0): 1, (12.5, 1): 2, (12.5, -1): 3}
 
 
-@pytest.mark.parametrize("strategy", ["small", "large"])
+@pytest.mark.parametrize("strategy", ["small", "large", "large_one_lane"])
 @pytest.mark.parametrize("name", MAP_NAMES)
 def test_lane_following_step_equals_the_reference(name, strategy, compiled_maps):
     import torch

@@ -45,9 +45,9 @@ def _make(name, E, N, nets, compiled_maps, seed, **cfg_kw):
 ])
 @pytest.mark.parametrize("cut", ["large", "large_one_lane"])
 def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, extra, cut, nets, compiled_maps):
-    """Both cuts of the LARGE form on every map: "large" picks by the map (teams where lanes split, one lane per
-    vehicle + slow lists on loop), "large_one_lane" forces the latter — on 4lane / minicity a third of the vehicles
-    then goes through the slow lists (branchings, junction roads, new roads)."""
+    """Both cuts of the LARGE form on every map: "large" picks by map and size (teams where lanes split or the batch
+    is below 65 536 vehicles, else one lane per vehicle + slow lists), "large_one_lane" forces the latter — on 4lane /
+    minicity a third of the vehicles then goes through the slow lists (branchings, junction roads, new roads)."""
     import torch
 
     from smarts_amd.lidar import Planar100
@@ -55,10 +55,8 @@ def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, e
     extra = dict(extra)
     if extra.get("lidar") == "planar100":
         extra["lidar"] = Planar100
-    if cut == "large_one_lane" and name == "loop":
-        pytest.skip("loop's lanes never split: \"large\" is the one-lane cut there")
     sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, launch_strategy=cut, **extra)
-    assert sim.launch_form() == ("large_one_lane" if (cut == "large_one_lane" or name == "loop") else "large_teams")
+    assert sim.launch_form() == ("large_one_lane" if cut == "large_one_lane" else "large_teams")  # (batches this small: teams)
     d, o = _host(sim.reset()), ob.reset_observe()
     assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
     rng = np.random.default_rng(seed)
@@ -94,7 +92,7 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
     spawns = make_spawns(cm, E, N, episodes=3, seed=21)
     sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
                                      launch_strategy=s, **extra), spawns=spawns) for s in ("small", "large", "large_one_lane")]
-    assert [s.launch_form() for s in sims] == ["small", "large_one_lane" if name == "loop" else "large_teams", "large_one_lane"]
+    assert [s.launch_form() for s in sims] == ["small", "large_teams", "large_one_lane"]
     rng = np.random.default_rng(21)
     for s in sims:
         s.reset()
@@ -155,3 +153,24 @@ def test_batches_above_the_threshold_agree_with_small_slices(name, E, N, sub, ti
         first, last = (a[:, :sub], a[:, E - sub:]) if k == "learner" else (a[:sub], a[E - sub:])
         assert np.array_equal(first, b, equal_nan=True) and np.array_equal(last, b, equal_nan=True), k
     sim.close(), sim2.close()
+
+
+def test_the_large_form_picks_its_cut_by_map_and_size(compiled_maps):
+    """smx_launch_form: one lane per vehicle + slow lists from 65 536 vehicles on where the map's lanes never split (loop,
+    whose junction-internal connector lanes have one successor each); teams below that and on maps with branchings."""
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    def form(name, E, N, strategy="auto"):
+        cm = compiled_maps(name)
+        sim = BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, launch_strategy=strategy),
+                         spawns=make_spawns(cm, E, N, episodes=1, seed=5))
+        f = sim.launch_form()
+        sim.close()
+        return f
+
+    assert form("loop", 64, 8) == "small"
+    assert form("loop", 1024, 32) == "large_teams"
+    assert form("loop", 2048, 32) == "large_one_lane"
+    assert form("4lane", 4200, 16) == "large_teams"
+    assert form("loop", 1024, 32, "large_one_lane") == "large_one_lane"
+    assert form("loop", 2048, 32, "large_teams") == "large_teams"
