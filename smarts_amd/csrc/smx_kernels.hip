@@ -72,6 +72,8 @@ struct KernelArgs {
   int keep_reward_done;     // auto-reset: the terminal step's reward / done / env_done stay
   int reset_all;            // k_reset: every env (explicit reset with NULL mask)
   double heading_gain_pos, lateral_gain_pos;  // lateral gains for target_speed > 0
+  int wp_pool_limit;        // k_waypoints_emit: records of its LDS pool in use (SMX_WPE_POOL; less: developer / tests)
+  char* wp_spill;           // k_waypoints_emit: knot records of the paths its LDS pool has no room for, [workgroup][column][11] + lanes
   int walk_new;             // k_first: also walk the new vehicles' knot lists (large batches: for the next tick's k_control_fast)
   double nb_d2_max;         // the largest squared distance whose rounded square root is <= cfg.nb_radius (radius_threshold)
   int debug_skip;
@@ -2539,13 +2541,17 @@ __device__ __forceinline__ void waypoints_tables_role(const KernelArgs& a, const
 // more sends the teams that do not fit to the slow list, whose kernel is a launch of pure latency at the end of the tick's
 // longest chain: at 320 a dozen workgroups of 8 192 overflowed per tick (76 us each tick for 200 vehicles); two sweeps of
 // the pool inside the kernel kept the knots in registers across the sweep (256 registers, one wavefront per SIMD).
+#ifndef SMX_WPE_POOL  // (a developer build with a small pool drives most paths through the overflow area: tests)
 #define SMX_WPE_POOL 352
+#endif
 struct __align__(8) WpKnot {
   double x, y, h, cum;  // position, unwrapped heading, arclength from the projected start
 };
 struct WpKnotLanes {
   short lane, strict;   // the knot's lane; lane of the last knot with an arclength strictly below this one's
 };
+// the overflow area of one workgroup: per column SMX_WPE_KNOTS + 1 records, then as many lane pairs
+#define SMX_WPE_SPILL_GROUP_BYTES ((size_t)SMX_BLOCK * (SMX_WPE_KNOTS + 1) * (sizeof(WpKnot) + sizeof(WpKnotLanes)))
 
 __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const int block) {
   // 15.6 KB of LDS in all: ten workgroups per CU (its registers allow twelve: three wavefronts per SIMD)
@@ -2562,6 +2568,8 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   __shared__ unsigned char hdr_one_lane[SMX_BLOCK];
   __shared__ double first_wp[SMX_WPT_VEHICLES][3];
   __shared__ unsigned char rows_live[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS], rows_zero[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];
+  __shared__ unsigned char rows_spill[SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS];  // rows whose knots lie in the overflow area
+  __shared__ unsigned char hdr_spill[SMX_BLOCK];
   static_assert(SMX_WPT_VEHICLES * SMX_WPT_MAX_PATHS <= 256, "row numbers are bytes");
   static_assert(sizeof(WpKnot) == 32 && sizeof(WpKnotLanes) == 4, "WpKnot layout");
   const smx_config& c = a.cfg;
@@ -2706,7 +2714,14 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     }
   }
   const int off = incl - (tabled_path ? nrec : 0);
-  if (tabled_path && off + nrec > SMX_WPE_POOL) tabled_path = false;  // the pool is full (sized so that it seldom is)
+  // The pool is full (a workgroup whose sixteen vehicles all sit in a bend: one or two of 8 192 per tick): the path's
+  // records go to the workgroup's overflow area in device memory instead, and its rows are swept after the others by
+  // a plain loop that reads them back (L2).  The rows list's serial emitter — 50 us of one team's latency behind this
+  // kernel, at the end of the tick's longest chain, on two ticks of three — is left to the teams that need it.
+  const bool spilled = tabled_path && off + nrec > a.wp_pool_limit && a.wp_spill != nullptr;
+  if (tabled_path && off + nrec > a.wp_pool_limit && !spilled) tabled_path = false;
+  WpKnot* const spill_knots = reinterpret_cast<WpKnot*>(a.wp_spill + (size_t)block * SMX_WPE_SPILL_GROUP_BYTES);
+  WpKnotLanes* const spill_lanes = reinterpret_cast<WpKnotLanes*>(spill_knots + (size_t)SMX_BLOCK * (SMX_WPE_KNOTS + 1));
   // A team with a row the pool does not hold (more knots than the table form takes, a cut knot list, a full pool), or
   // that has to number its paths the long way (a branching inside the lookahead, a road of more than four lanes),
   // leaves all its rows and its trip meter to k_waypoints_listed: its vehicle goes to the slow list.
@@ -2772,27 +2787,51 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     r.y = k0y;
     r.h = k0h;
     r.cum = 0.0;
-    pool[off] = r;
     WpKnotLanes rl;
     rl.lane = (short)lane0;
     rl.strict = (short)lane0;
-    pool_lanes[off] = rl;
+    if (!spilled) {
+      pool[off] = r;
+      pool_lanes[off] = rl;
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      if (k + 1 < nrec) {
-        WpKnot q;
-        q.x = kx[k];
-        q.y = ky[k];
-        q.h = kh[k];
-        q.cum = cum[k];
-        pool[off + k + 1] = q;
-        WpKnotLanes ql;
-        ql.lane = (short)kl[k];
-        ql.strict = (short)kstrict[k];
-        pool_lanes[off + k + 1] = ql;
+      for (int k = 0; k < KP; ++k) {
+        if (k + 1 < nrec) {
+          WpKnot q;
+          q.x = kx[k];
+          q.y = ky[k];
+          q.h = kh[k];
+          q.cum = cum[k];
+          pool[off + k + 1] = q;
+          WpKnotLanes ql;
+          ql.lane = (short)kl[k];
+          ql.strict = (short)kstrict[k];
+          pool_lanes[off + k + 1] = ql;
+        }
+      }
+    } else {
+      WpKnot* gk = spill_knots + col * (SMX_WPE_KNOTS + 1);
+      WpKnotLanes* gl = spill_lanes + col * (SMX_WPE_KNOTS + 1);
+      gk[0] = r;
+      gl[0] = rl;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (k + 1 < nrec) {
+          WpKnot q;
+          q.x = kx[k];
+          q.y = ky[k];
+          q.h = kh[k];
+          q.cum = cum[k];
+          gk[k + 1] = q;
+          WpKnotLanes ql;
+          ql.lane = (short)kl[k];
+          ql.strict = (short)kstrict[k];
+          gl[k + 1] = ql;
+        }
       }
     }
   }
+  hdr_spill[col] = spilled ? 1 : 0;
+  __threadfence_block();  // (the overflow area is read back by other lanes of the workgroup)
   __syncthreads();
   SMX_TSTAMP(te3);
   SMX_TACC(34, te2, te3);
@@ -2804,7 +2843,7 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
   // the four dependency chains — header, interval search, two knot records, three divisions, the heading wrap — are
   // independent, and straight-line code is what lets the compiler interleave them (a wavefront alone on its SIMD half
   // the time issues one chain's instruction every ten cycles or so).  Only the rare lane look-ups keep their branch.
-  int n_rows_live = 0, n_rows_zero = 0;  // (uniform: the workgroup is one wavefront)
+  int n_rows_live = 0, n_rows_zero = 0, n_rows_spill = 0;  // (uniform: the workgroup is one wavefront)
   {
     static_assert(SMX_BLOCK == 64, "one ballot per 64 rows");
     const int n_rows = SMX_WPT_VEHICLES * P;
@@ -2812,11 +2851,14 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
     for (int r0 = 0; r0 < n_rows; r0 += SMX_BLOCK) {
       const int r = r0 + (int)threadIdx.x;
       const int src = r < n_rows ? (int)book.src[r] : (int)SMX_ROW_SKIP;
-      const unsigned long long ml = __ballot(src >= 0), mz = __ballot(src == SMX_ROW_ZERO);
-      if (src >= 0) rows_live[n_rows_live + __popcll(ml & below)] = (unsigned char)r;
+      const bool in_pool = src >= 0 && hdr_spill[src] == 0, in_spill = src >= 0 && hdr_spill[src] != 0;
+      const unsigned long long ml = __ballot(in_pool), mz = __ballot(src == SMX_ROW_ZERO), ms = __ballot(in_spill);
+      if (in_pool) rows_live[n_rows_live + __popcll(ml & below)] = (unsigned char)r;
       if (src == SMX_ROW_ZERO) rows_zero[n_rows_zero + __popcll(mz & below)] = (unsigned char)r;
+      if (in_spill) rows_spill[n_rows_spill + __popcll(ms & below)] = (unsigned char)r;
       n_rows_live += __popcll(ml);
       n_rows_zero += __popcll(mz);
+      n_rows_spill += __popcll(ms);
     }
   }
   __syncthreads();
@@ -2955,6 +2997,70 @@ __device__ __forceinline__ void waypoints_emit_role(const KernelArgs& a, const i
       SMX_TSTAMP(tr2);
       SMX_TACC(38, tr0, tr1);
       SMX_TACC(39, tr1, tr2);
+    }
+    // the rows whose knots lie in the overflow area (seldom any): the same expressions, one slot at a time, the knot
+    // records read back from device memory
+    if (n_rows_spill > 0) {
+      int ridx = threadIdx.x / W, i = threadIdx.x - ridx * W;
+      for (int e = threadIdx.x; e < n_rows_spill * W; e += SMX_BLOCK) {
+        const int row = rows_spill[ridx];
+        const int vq = small_quotient(row, rcp_p), slot_q = row - vq * P;
+        const int sc = (int)book.src[row];
+        const bool have = i < (int)book.count[row];
+        const WpKnot* gk = spill_knots + sc * (SMX_WPE_KNOTS + 1);
+        const WpKnotLanes* gl = spill_lanes + sc * (SMX_WPE_KNOTS + 1);
+        const int n = hdr_n[sc], nr = max((int)hdr_nrec[sc], 1);
+        const double t = (i == n - 1) ? hdr_D[sc] : (double)i * hdr_step[sc];
+        int j = 0;
+        for (int k = 1; k < nr; ++k) j += (gk[k].cum <= t) ? 1 : 0;
+        const bool interior = j + 1 < nr;
+        const WpKnot K = gk[j];
+        const WpKnot Q = gk[interior ? j + 1 : j];
+        const WpKnotLanes KL = gl[j], QL = gl[interior ? j + 1 : j];
+        const double den = interior ? Q.cum - K.cum : 1.0;
+        const double dt_ = t - K.cum;
+        const double sx = (Q.x - K.x) / den, sy = (Q.y - K.y) / den, sh = (Q.h - K.h) / den;
+        double h = interior ? sh * dt_ + K.h : K.h;
+        h = (n == 1) ? h : wrap_heading(h);
+        const double ox = have ? (interior ? sx * dt_ + K.x : K.x) : 0.0;
+        const double oy = have ? (interior ? sy * dt_ + K.y : K.y) : 0.0;
+        const double oh = have ? h : 0.0;
+        float ow = have ? hdr_w0[sc] : 0.0f, os = have ? hdr_s0[sc] : 0.0f;
+        const int oln = have ? ((t == K.cum) ? (int)KL.strict : (int)KL.lane) : -1;
+        int oli = have ? (int)hdr_li0[sc] : 0;
+        if (have && hdr_one_lane[sc] == 0) {
+          double wj = m.lane_width[KL.lane], sj = m.lane_speed[KL.lane];
+          if (interior && QL.lane != KL.lane) {
+            const double sw = (m.lane_width[QL.lane] - wj) / den, ss = (m.lane_speed[QL.lane] - sj) / den;
+            wj = sw * dt_ + wj;
+            sj = ss * dt_ + sj;
+          }
+          ow = (float)wj;
+          os = (float)sj;
+          oli = m.lane_index[oln];
+        }
+        if (have && i == 0 && slot_q == 0) {
+          first_wp[vq][0] = ox;
+          first_wp[vq][1] = oy;
+          first_wp[vq][2] = oh;
+        }
+        const size_t q = ((size_t)book.veh[vq] * P + slot_q) * W + i;
+        double* dst = o.wp_pos + q * 3;
+        dst[0] = ox;
+        dst[1] = oy;
+        dst[2] = 0.0;
+        o.wp_heading[q] = (float)oh;
+        o.wp_lane_width[q] = ow;
+        o.wp_speed_limit[q] = os;
+        o.wp_lane_id[q] = (int16_t)oln;
+        o.wp_lane_index[q] = (int8_t)oli;
+        ridx += drow;
+        i += di;
+        if (i >= W) {
+          i -= W;
+          ++ridx;
+        }
+      }
     }
     SMX_TSTAMP(te4);
     SMX_TACC(35, te3, te4);
@@ -4502,6 +4608,8 @@ struct smx_handle_s {
   void* map_blob;  // one device allocation holding every table
   size_t map_bytes;
   void* knots_blob;  // KnotLists of the waypoints sensor (k_wp_walk -> k_waypoints_tables)
+  void* spill_blob;  // k_waypoints_emit's overflow area (KernelArgs::wp_spill)
+  int wp_pool_limit; // records of k_waypoints_emit's LDS pool in use (smx_debug_set_wp_pool)
   int32_t* alive_blob;  // [total] alive list + two counters (ticks alternate), large batches
   uint8_t* pending_blob;  // [total] seed_pending
   int32_t* slow_blob;   // [4][total] slow lists of the fast kernels (scan facts, scan seeds, control, waypoint rows) + [2][4] counters (ticks alternate)
@@ -4605,6 +4713,8 @@ static int create_impl(const smx_config* cfg, int device, smx_handle* out) {
   h->map_blob = nullptr;
   h->map_bytes = 0;
   h->knots_blob = nullptr;
+  h->spill_blob = nullptr;
+  h->wp_pool_limit = SMX_WPE_POOL;
   h->alive_blob = nullptr;
   h->scan_carry = nullptr;
   h->slow_blob = nullptr;
@@ -4906,6 +5016,13 @@ extern "C" int smx_load_map(smx_handle h, const smx_map_tables* t) {
     h->knots.key = (int32_t*)(kb + off_key);
     h->knots.cnt = (uint8_t*)(kb + off_cnt);
     h->knots.nk16 = (uint8_t*)(kb + off_nk16);
+  }
+  if ((h->cfg.sensors & SMX_SENSOR_WAYPOINTS) && !h->spill_blob) {
+    // a region of (SMX_WPE_KNOTS + 1) knot records + lanes per column of every k_waypoints_emit workgroup: 1.6 KB per
+    // vehicle (the outputs are 8 KB), touched only by the few workgroups of a tick whose paths outgrow the LDS pool
+    const size_t tv = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
+    const size_t groups = (tv + SMX_WPT_VEHICLES - 1) / SMX_WPT_VEHICLES;
+    SMX_HIP(hipMalloc(&h->spill_blob, groups * SMX_WPE_SPILL_GROUP_BYTES));
   }
   if (!h->status_dev) {
     SMX_HIP(hipMalloc((void**)&h->status_dev, sizeof(int32_t)));
@@ -5244,6 +5361,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
   a.heading_gain_pos = h->heading_gain_pos;
   a.nb_d2_max = h->nb_d2_max;
   a.walk_new = 0;
+  a.wp_spill = (char*)h->spill_blob;
+  a.wp_pool_limit = h->wp_pool_limit;
   a.lateral_gain_pos = h->lateral_gain_pos;
   a.debug_skip = h->debug_skip;
   a.knots = h->knots;
@@ -5655,6 +5774,15 @@ extern "C" int smx_debug_slow_counts(smx_handle h, int32_t* out4) {
   return SMX_OK;
 }
 
+// developer / tests: use only `records` of k_waypoints_emit's LDS knot pool (0 < records <= SMX_WPE_POOL), so that
+// small batches reach its overflow area too (a full pool needs sixteen vehicles in a bend in one workgroup)
+extern "C" int smx_debug_set_wp_pool(smx_handle h, int32_t records) {
+  if (!h) return SMX_ERR_INVALID;
+  if (records < 1 || records > SMX_WPE_POOL) return fail(h, SMX_ERR_INVALID, "smx_debug_set_wp_pool: 1 .. SMX_WPE_POOL records");
+  h->wp_pool_limit = records;
+  return SMX_OK;
+}
+
 extern "C" int smx_set_timing(smx_handle h, int level) {
   if (!h) return SMX_ERR_INVALID;
   h->timing = level == 1;
@@ -5714,6 +5842,7 @@ extern "C" void smx_destroy(smx_handle h) {
   if (h->scan_carry) (void)hipFree(h->scan_carry);
   if (h->slow_blob) (void)hipFree(h->slow_blob);
   if (h->pending_blob) (void)hipFree(h->pending_blob);
+  if (h->spill_blob) (void)hipFree(h->spill_blob);
   if (h->ctrl_blob) (void)hipFree(h->ctrl_blob);
   if (h->status_dev) (void)hipFree(h->status_dev);
   if (h->side_ready) {

@@ -174,3 +174,36 @@ def test_the_large_form_picks_its_cut_by_map_and_size(compiled_maps):
     assert form("4lane", 4200, 16) == "large_teams"
     assert form("loop", 1024, 32, "large_one_lane") == "large_one_lane"
     assert form("loop", 2048, 32, "large_teams") == "large_teams"
+
+
+def test_rows_from_the_overflow_area_equal_the_small_forms(compiled_maps):
+    """k_waypoints_emit keeps the knot records of its workgroup's paths in an LDS pool; the paths that do not fit go
+    through an overflow area in device memory and a sweep of their own.  With the pool cut to 40 records nearly every
+    workgroup overflows: every row must still equal the SMALL form's, bit for bit, over auto-reset ticks."""
+    import ctypes as C
+
+    import torch
+
+    from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
+
+    for name, N in (("loop", 32), ("minicity", 16)):
+        cm = compiled_maps(name)
+        E = 256 // N
+        spawns = make_spawns(cm, E, N, episodes=3, seed=31)
+        sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
+                                         launch_strategy=s), spawns=spawns) for s in ("small", "large_one_lane")]
+        sims[1].lib.smx_debug_set_wp_pool.argtypes = [C.c_void_p, C.c_int32]
+        assert sims[1].lib.smx_debug_set_wp_pool(sims[1].handle, 40) == 0
+        rng = np.random.default_rng(31)
+        for s in sims:
+            s.reset()
+        for t in range(60):
+            acts = torch.from_numpy(_actions(rng, E, N)).cuda()
+            outs = [s.step(acts) for s in sims]
+            if t % 7 == 0 or t == 59:
+                torch.cuda.synchronize()
+                for k in outs[0]:
+                    assert np.array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), equal_nan=True), (name, t, k)
+                assert np.array_equal(sims[0].state.cpu().numpy(), sims[1].state.cpu().numpy(), equal_nan=True), (name, t)
+        for s in sims:
+            s.close()
