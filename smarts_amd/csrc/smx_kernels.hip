@@ -4251,36 +4251,52 @@ __global__ void __launch_bounds__(SMX_FIRST_BLOCK) k_first(const KernelArgs a) {
     const int f = a.st.flags[g0 + threadIdx.x];
     mine_first = (f & SMX_F_ALIVE) && (f & SMX_F_FIRST);
   }
-  if (!__syncthreads_or(mine_first)) return;
+  const int n_new = __syncthreads_count(mine_first);
+  if (n_new == 0) return;
   SMX_TSTAMP(tk0);
+  // More new vehicles than one round of (vehicle, scan half) teams holds (a 64-vehicle env of C5: 128 pairs for 64
+  // teams): the seeds halves take the round — the waypoint rows wait for nothing else —, and the facts halves
+  // then run BESIDE the rows' serial emitter (minicity: 220 us of a restarted env's 410) on the
+  // workgroup's other four wavefronts; observe needs both.  Fewer: one round serves both halves as before.
+  const bool split = 2 * n_new > SMX_FIRST_BLOCK / SMX_TEAM;
   // The workgroup is four wavefronts wide: a restarted env's chain scan -> sensors -> commit is
   // pure latency, so its independent pieces run side by side — (vehicle, scan half) pairs over the
   // teams of all four wavefronts, then the vehicles' waypoint teams — instead of one after the
   // other in a single wavefront (an env of 16 vehicles: 4 scan rounds of ~40 us became 1).
   // ---- scan: one team per (vehicle, half)
-  {
-    const size_t pairs = (g1 - g0) * 2;
-    for (size_t p0 = 0; p0 < pairs; p0 += SMX_FIRST_BLOCK / SMX_TEAM) {
-      const size_t pr = p0 + threadIdx.x / SMX_TEAM;
-      if (pr < pairs) {
-        const size_t gid = g0 + (pr >> 1);
-        const int flags = a.st.flags[gid];
-        if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role<SMX_TEAM, true>(a, m, c, gid, total, team_rank<SMX_TEAM>(), flags, (int)(pr & 1));
+  // (one scan call site inside a two-turn loop: inlined three times the kernel spilled 2 KB per lane)
+#pragma nounroll
+  for (int turn = 0; turn < 2; ++turn) {
+    SMX_TSTAMP(tt0);
+    // turn 0: every team scans — both halves of a vehicle (pair = 2 x vehicle + half), or the seeds halves only;
+    // turn 1: the first 256 threads emit the rows, and the other 32 teams take the facts halves left over
+    const bool scans = turn == 0 || (split && threadIdx.x >= SMX_FIRST_WP_THREADS);
+    if (scans) {
+      const int teams = turn == 0 ? SMX_FIRST_BLOCK / SMX_TEAM : (SMX_FIRST_BLOCK - SMX_FIRST_WP_THREADS) / SMX_TEAM;
+      const int team = ((int)threadIdx.x - (turn == 0 ? 0 : SMX_FIRST_WP_THREADS)) / SMX_TEAM;
+      const bool both = turn == 0 && !split;
+      const size_t units = both ? (g1 - g0) * 2 : (g1 - g0);
+      for (size_t u0 = 0; u0 < units; u0 += teams) {
+        const size_t u = u0 + team;
+        if (u < units) {
+          const size_t gid = g0 + (both ? (u >> 1) : u);
+          const int half = both ? (int)(u & 1) : (turn == 0 ? 1 : 0);
+          const int flags = a.st.flags[gid];
+          if ((flags & SMX_F_ALIVE) && (flags & SMX_F_FIRST)) scan_role<SMX_TEAM, true>(a, m, c, gid, total, team_rank<SMX_TEAM>(), flags, half);
+        }
+      }
+    } else if (turn == 1 && threadIdx.x < SMX_FIRST_WP_THREADS) {  // (whole wavefronts; waypoints_for holds no barrier)
+      for (size_t base = g0; base < g1; base += SMX_FIRST_WP_THREADS / SMX_WP_LANES) {
+        const size_t gid = base + threadIdx.x / SMX_WP_LANES;
+        if (gid < g1) waypoints_for<SMX_FIRST_WP_THREADS>(a, gid, knot_scratch + threadIdx.x);
       }
     }
+    __threadfence();
+    __syncthreads();
+    SMX_TSTAMP(tt1);
+    SMX_TACC_ALL(turn == 0 ? 57 : 58, tt0, tt1);
   }
-  __threadfence();
-  __syncthreads();
-  SMX_TSTAMP(tk1);
-  SMX_TACC_ALL(57, tk0, tk1);
-  // ---- sensors
-  if (threadIdx.x < SMX_FIRST_WP_THREADS)  // (whole wavefronts; waypoints_for holds no barrier)
-    for (size_t base = g0; base < g1; base += SMX_FIRST_WP_THREADS / SMX_WP_LANES) {
-      const size_t gid = base + threadIdx.x / SMX_WP_LANES;
-      if (gid < g1) waypoints_for<SMX_FIRST_WP_THREADS>(a, gid, knot_scratch + threadIdx.x);
-    }
   SMX_TSTAMP(tk2);
-  SMX_TACC_ALL(58, tk1, tk2);
   observe_role(a, block);
   SMX_TSTAMP(tk3);
   SMX_TACC_ALL(59, tk2, tk3);

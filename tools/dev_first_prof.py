@@ -22,7 +22,7 @@ for i in range(warm): sim.step(actions[i % bench.ACTION_CYCLE])
 torch.cuda.synchronize(); buf = (ctypes.c_ulonglong * 128)(); lib.smx_prof_read(buf, 1)
 for i in range(T): sim.step(actions[(warm + i) % bench.ACTION_CYCLE])
 torch.cuda.synchronize(); lib.smx_prof_read(buf, 1)
-names = {57: 'scan (both halves, team rounds)', 58: 'waypoint rows (serial emitter)', 59: 'observe', 60: 'commit', 61: 'scan .. commit'}
+names = {57: 'scan round (both halves, or the seeds halves)', 58: 'waypoint rows (beside them the facts halves left over)', 59: 'observe', 60: 'commit', 61: 'scan .. commit'}
 print(f"{config}: k_first workgroups that found new vehicles, ticks {warm}-{warm + T} ({sim.launch_form()})")
 for k in sorted(names):
     if buf[k + 64]:
