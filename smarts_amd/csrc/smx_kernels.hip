@@ -4382,9 +4382,19 @@ __global__ void __launch_bounds__(SMX_BLOCK) k_road_waypoints(const KernelArgs a
   lanes.n = 0;
   // road_map.nearest_lane(point) (road_map.py:91-96, the default radius); asked here rather than taken from
   // k_scan so that the kernel also serves the reset pass, whose scan runs inside k_first
-  const RoadFacts nf = road_facts_scan(m, px, py, fmax(10.0, 2.0 * m.default_lane_width), 0, nullptr, nullptr);
-  if (nf.lane >= 0) {
-    const int road = m.lane_road[nf.lane];
+  // In a tick the scan's facts half has just answered it (the nearest lane and its distance: the observe role reads
+  // its ego lane the same way); only the reset pass, whose scan runs inside k_first after this kernel, asks here —
+  // every lane of the team repeating a one-lane ring search was the longest piece of the kernel.
+  int near_lane = -1;
+  if (!a.first_only) {
+    const int ln = a.st.facts_i32[(size_t)SMX_FI_LANE * total + gid];
+    const double dd = a.st.facts_f64[(size_t)SMX_FF_LANE_DIST * total + gid];
+    near_lane = (ln >= 0 && dd < fmax(10.0, 2.0 * m.default_lane_width)) ? ln : -1;
+  } else {
+    near_lane = road_facts_scan(m, px, py, fmax(10.0, 2.0 * m.default_lane_width), 0, nullptr, nullptr).lane;
+  }
+  if (near_lane >= 0) {
+    const int road = m.lane_road[near_lane];
     lanes.add_road(m, road);
     for (int k = m.road_par_off[road]; k < m.road_par_off[road + 1]; ++k) lanes.add_road(m, m.road_par_idx[k]);
     // Road.oncoming_roads_at_point (sumo_road_network.py:596-605)
