@@ -505,9 +505,10 @@ enum { SMX_LAUNCH_AUTO = 0, SMX_LAUNCH_SMALL = 1, SMX_LAUNCH_LARGE = 2,
 int smx_set_launch_strategy(smx_handle h, int strategy);
 /* The form the next tick will run in (after smx_load_map): the LARGE form comes in two cuts — one lane per vehicle
  * seeded by last tick's answers with the rare cases on device-side slow lists, where the map's lanes never split
- * (no lanepoint with several successors: loop) and the batch has at least 65 536 vehicles, and teams of lanes per
- * vehicle for everybody otherwise (intersections, minicity: a third of the vehicles would be "rare cases"; smaller
- * batches: the team kernels' chain of launches is the shorter one).  Same results either way. */
+ * (no lanepoint with several successors: loop), and teams of lanes per vehicle for everybody where they do
+ * (intersections, minicity: a third of the vehicles would be "rare cases").  Inside the one-lane cut the path-seeds
+ * search is the one-lane kernel from 114 688 vehicles on and the team kernel below (its slow chain's latency would
+ * end the tick of a smaller batch).  Same results either way. */
 enum { SMX_FORM_SMALL = 0, SMX_FORM_LARGE_TEAMS = 1, SMX_FORM_LARGE_ONE_LANE = 2 };
 int smx_launch_form(smx_handle h);
 const char* smx_version(void);

@@ -3858,8 +3858,8 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
-#ifndef SMX_ONE_LANE_MIN_VEHICLES  // LARGE picks the one-lane cut from this many vehicles on (on a map whose lanes never split)
-#define SMX_ONE_LANE_MIN_VEHICLES 65536
+#ifndef SMX_ONE_LANE_MIN_VEHICLES  // the one-lane cut's seeds half is the one-lane kernel + slow chain from this many vehicles on
+#define SMX_ONE_LANE_MIN_VEHICLES 114688
 #endif
 #ifndef SMX_OGM_ENV_MIN_VEHICLES  // small form: OGM tiles by k_ogm_env from this many vehicles on (smarts_amd/engine.py mirrors it)
 #define SMX_OGM_ENV_MIN_VEHICLES 8192
@@ -4840,15 +4840,24 @@ extern "C" int smx_set_launch_strategy(smx_handle h, int strategy) {
 }
 
 // Which cut of the LARGE form a batch takes (smx.h, smx_launch_form): one lane per vehicle + slow lists where the lists
-// stay short (a map whose lanes never split) AND the batch is big enough for throughput to decide — below
-// SMX_ONE_LANE_MIN_VEHICLES the tick is a chain of single-wavefront latencies either way, and the team kernels' chain
-// is the shorter one (C4's 1024-env shard over a long run: 0.229 against 0.266 ms; 2048 envs: 0.274 against 0.289, but
-// 0.435 against 0.392 with nine agents in ten alive; 3072: 0.368 against 0.321); the strategies LARGE_ONE_LANE / LARGE_TEAMS force a cut.
+// stay short (a map whose lanes never split), teams of lanes for everybody elsewhere; the strategies LARGE_ONE_LANE /
+// LARGE_TEAMS force a cut.
 static bool one_lane_cut(const smx_handle_s* h) {
   if (h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) return true;
   if (h->launch_strategy == SMX_LAUNCH_LARGE_TEAMS) return false;
+  return !h->map_junctions;
+}
+// ... and, inside the one-lane cut, whether the seeds half is the one-lane kernel + the slow seeds chain, or the team
+// kernel for everybody: the chain — from-scratch searches and the serial emitter for the few vehicles the one-lane
+// kernel cannot serve — is 110 us of latency behind the seeds kernel whatever the batch, and below
+// SMX_ONE_LANE_MIN_VEHICLES it ends the tick; the team seeds kernel then costs less than it saves (C4's shards, default
+// run / ticks 5-65, ms per tick, team seeds against one-lane seeds: 1024 envs 0.195 / 0.265 against 0.266 / 0.284; 2048:
+// 0.251 / 0.378 against 0.288 / 0.383; 3072: 0.286 / 0.455 against 0.325 / 0.477; 4096: 0.367 / 0.603 against 0.380 / 0.579;
+// the team kernels throughout: 0.227 / 0.287, 0.273 / 0.435, 0.371 / 0.593, 0.440 / 0.768).
+static bool one_lane_seeds(const smx_handle_s* h) {
+  if (h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) return true;
   const size_t total = (size_t)h->cfg.num_envs * h->cfg.num_vehicles;
-  return !h->map_junctions && total >= SMX_ONE_LANE_MIN_VEHICLES;
+  return total >= SMX_ONE_LANE_MIN_VEHICLES;
 }
 
 extern "C" int smx_launch_form(smx_handle h) {
@@ -5505,7 +5514,7 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         ks.slow_count = slow_counters + 1;
       }
       // path seeds without the ten-nearest list: agents with a route object and no fixed route, waypoints sensor on
-      const bool fast_seeds = !SMX_WP_STAGED && fast && !routed && (c.sensors & SMX_SENSOR_WAYPOINTS) && h->pending_blob;
+      const bool fast_seeds = !SMX_WP_STAGED && fast && !routed && (c.sensors & SMX_SENSOR_WAYPOINTS) && h->pending_blob && one_lane_seeds(h);
       if (fast_seeds) {
         ks.seed_pending = h->pending_blob;
         kwp.seed_pending = h->pending_blob;

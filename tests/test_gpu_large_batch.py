@@ -45,9 +45,10 @@ def _make(name, E, N, nets, compiled_maps, seed, **cfg_kw):
 ])
 @pytest.mark.parametrize("cut", ["large", "large_one_lane"])
 def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, extra, cut, nets, compiled_maps):
-    """Both cuts of the LARGE form on every map: "large" picks by map and size (teams where lanes split or the batch
-    is below 65 536 vehicles, else one lane per vehicle + slow lists), "large_one_lane" forces the latter — on 4lane /
-    minicity a third of the vehicles then goes through the slow lists (branchings, junction roads, new roads)."""
+    """Both cuts of the LARGE form on every map: "large" picks by the map (teams where lanes split, else one lane per
+    vehicle + slow lists — with the team kernel for the path seeds at these sizes), "large_one_lane" forces the one-lane
+    cut with the one-lane seeds kernel and its slow chain — on 4lane / minicity a third of the vehicles then goes
+    through the slow lists (branchings, junction roads, new roads)."""
     import torch
 
     from smarts_amd.lidar import Planar100
@@ -56,7 +57,7 @@ def test_large_strategy_teacher_forced_against_the_oracle(name, E, N, T, seed, e
     if extra.get("lidar") == "planar100":
         extra["lidar"] = Planar100
     sim, ob, cfg = _make(name, E, N, nets, compiled_maps, seed, launch_strategy=cut, **extra)
-    assert sim.launch_form() == ("large_one_lane" if cut == "large_one_lane" else "large_teams")  # (batches this small: teams)
+    assert sim.launch_form() == ("large_one_lane" if (cut == "large_one_lane" or name == "loop") else "large_teams")
     d, o = _host(sim.reset()), ob.reset_observe()
     assert parity.compare(d, o, tol64=1e-9, tol32=2e-6, where="reset ") == []
     rng = np.random.default_rng(seed)
@@ -91,8 +92,8 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
     E = max(2, 192 // N)
     spawns = make_spawns(cm, E, N, episodes=3, seed=21)
     sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
-                                     launch_strategy=s, **extra), spawns=spawns) for s in ("small", "large", "large_one_lane")]
-    assert [s.launch_form() for s in sims] == ["small", "large_teams", "large_one_lane"]
+                                     launch_strategy=s, **extra), spawns=spawns) for s in ("small", "large", "large_one_lane", "large_teams")]
+    assert [s.launch_form() for s in sims] == ["small", "large_one_lane" if name == "loop" else "large_teams", "large_one_lane", "large_teams"]
     rng = np.random.default_rng(21)
     for s in sims:
         s.reset()
@@ -101,7 +102,7 @@ def test_strategies_agree_bit_for_bit(name, N, extra, compiled_maps):
         outs = [s.step(acts) for s in sims]
         if t % 13 == 0 or t == 39:
             torch.cuda.synchronize()
-            for other in (1, 2):
+            for other in (1, 2, 3):
                 for k in outs[0]:
                     assert np.array_equal(outs[0][k].cpu().numpy(), outs[other][k].cpu().numpy(), equal_nan=True), (t, k, other)
                 assert np.array_equal(sims[0].state.cpu().numpy(), sims[other].state.cpu().numpy(), equal_nan=True), (t, other)
@@ -156,8 +157,8 @@ def test_batches_above_the_threshold_agree_with_small_slices(name, E, N, sub, ti
 
 
 def test_the_large_form_picks_its_cut_by_map_and_size(compiled_maps):
-    """smx_launch_form: one lane per vehicle + slow lists from 65 536 vehicles on where the map's lanes never split (loop,
-    whose junction-internal connector lanes have one successor each); teams below that and on maps with branchings."""
+    """smx_launch_form: one lane per vehicle + slow lists where the map's lanes never split (loop, whose junction-internal
+    connector lanes have one successor each); teams on maps with branchings."""
     from smarts_amd.engine import BatchedSim, SimConfig, make_spawns
 
     def form(name, E, N, strategy="auto"):
@@ -169,10 +170,9 @@ def test_the_large_form_picks_its_cut_by_map_and_size(compiled_maps):
         return f
 
     assert form("loop", 64, 8) == "small"
-    assert form("loop", 1024, 32) == "large_teams"
-    assert form("loop", 2048, 32) == "large_one_lane"
+    assert form("loop", 1024, 32) == "large_one_lane"
     assert form("4lane", 4200, 16) == "large_teams"
-    assert form("loop", 1024, 32, "large_one_lane") == "large_one_lane"
+    assert form("4lane", 4200, 16, "large_one_lane") == "large_one_lane"
     assert form("loop", 2048, 32, "large_teams") == "large_teams"
 
 

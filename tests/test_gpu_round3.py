@@ -43,7 +43,7 @@ def test_strategies_agree_bit_for_bit_on_a_long_sparse_run(name, E, N, ticks, ex
     spawns = make_spawns(cm, E, N, episodes=3, seed=77)
     sims = [BatchedSim(cm, SimConfig(num_envs=E, num_vehicles=N, neighbors=True, nb_radius=50.0, auto_reset=True,
                                      launch_strategy=s, **_extra(extra)), spawns=spawns)
-            for s in ("small", "large", "large_one_lane")]  # (4 608-5 120 vehicles: "large" is the team cut)
+            for s in ("small", "large", "large_one_lane")]  # ("large": by the map; at these sizes with the team seeds kernel)
     rng = np.random.default_rng(77)
     for s in sims:
         s.reset()
