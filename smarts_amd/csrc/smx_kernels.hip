@@ -3858,6 +3858,9 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_ONE_LANE_ON_SPLIT_MAPS  // developer: the one-lane cut on maps whose lanes split too
+#define SMX_ONE_LANE_ON_SPLIT_MAPS 0
+#endif
 #ifndef SMX_ONE_LANE_MIN_VEHICLES  // the one-lane cut's seeds half is the one-lane kernel + slow chain from this many vehicles on
 #define SMX_ONE_LANE_MIN_VEHICLES 114688
 #endif
@@ -4845,7 +4848,7 @@ extern "C" int smx_set_launch_strategy(smx_handle h, int strategy) {
 static bool one_lane_cut(const smx_handle_s* h) {
   if (h->launch_strategy == SMX_LAUNCH_LARGE_ONE_LANE) return true;
   if (h->launch_strategy == SMX_LAUNCH_LARGE_TEAMS) return false;
-  return !h->map_junctions;
+  return !h->map_junctions || SMX_ONE_LANE_ON_SPLIT_MAPS;
 }
 // ... and, inside the one-lane cut, whether the seeds half is the one-lane kernel + the slow seeds chain, or the team
 // kernel for everybody: the chain — from-scratch searches and the serial emitter for the few vehicles the one-lane
