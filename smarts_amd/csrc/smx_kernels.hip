@@ -1482,16 +1482,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SPLIT ? 2 : SMX_SCAN_WAVES, 8
 // One half of the scan as a launch of its own (large batches): the road facts feed the observe role only and
 // the path seeds the waypoint kernels only, so the two go to different streams and each keeps the registers
 // it needs (the facts half alone fits more wavefronts per SIMD than the pair).
-template <int ROLE, bool ROUTED = false>
+// (TEAM: four lanes a vehicle when the batch fills the chip, eight up to SMX_SCAN_WIDE_MAX_VEHICLES on maps whose lanes
+// split: a quarter-full chip is bound by one team's latency, and the wider team's is the shorter)
+template <int ROLE, bool ROUTED = false, int TEAM = SMX_TEAM_LARGE>
 __global__ void __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 4 : 3, 8))) __launch_bounds__(SMX_BLOCK) k_scan_half(const KernelArgs a) {
   const smx_config& c = a.cfg;
   const size_t total = (size_t)c.num_envs * c.num_vehicles;
-  const size_t gid = launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_TEAM_LARGE, total);
+  const size_t gid = launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / TEAM, total);
   if (gid >= total) return;
   const int flags = a.st.flags[gid];
   if (!(flags & SMX_F_ALIVE)) return;
   if (a.first_only && !(flags & SMX_F_FIRST)) return;
-  scan_role<SMX_TEAM_LARGE, ROUTED>(a, a.map, c, gid, total, team_rank<SMX_TEAM_LARGE>(), flags, ROLE);
+  scan_role<TEAM, ROUTED>(a, a.map, c, gid, total, team_rank<TEAM>(), flags, ROLE);
 }
 
 // k_scan_fast (large batches): one half of the scan with ONE lane per vehicle (smx_scan.h facts_one_lane /
@@ -3858,6 +3860,9 @@ struct OgmPose {
   int alive, observes;
 };
 #define SMX_OGM_WAVES 4
+#ifndef SMX_SCAN_WIDE_MAX_VEHICLES  // the team scan halves take eight lanes a vehicle up to this many vehicles, four above
+#define SMX_SCAN_WIDE_MAX_VEHICLES 65536
+#endif
 #ifndef SMX_ONE_LANE_ON_SPLIT_MAPS  // developer: the one-lane cut on maps whose lanes split too
 #define SMX_ONE_LANE_ON_SPLIT_MAPS 0
 #endif
@@ -5505,6 +5510,10 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       // the scan's halves as two launches, on two streams when forked: path seeds (-> waypoint kernels) on the
       // caller's, road facts (-> observe) on side 1
       const unsigned half_blocks = (unsigned)((total * SMX_TEAM_LARGE + SMX_BLOCK - 1) / SMX_BLOCK);
+      // (where the searches are long — lanes that split and cross: 4lane 2048 x 16 0.430 -> 0.393 ms; on loop the four-lane
+      // teams stay: 32 768 vehicles 0.260 either way, 65 536 0.371 against 0.378)
+      const bool wide_teams = h->map_junctions && total <= SMX_SCAN_WIDE_MAX_VEHICLES;
+      const unsigned wide_blocks = (unsigned)((total * SMX_TEAM + SMX_BLOCK - 1) / SMX_BLOCK);
       const bool fast = fast_scan && k.alive_list != nullptr && !k.first_only && h->slow_blob && !SMX_SCAN_UNSEEDED;
       const unsigned fast_blocks = (unsigned)((total + SMX_BLOCK - 1) / SMX_BLOCK);
       kf = k;
@@ -5546,6 +5555,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
         }
       } else if (routed)
         hipLaunchKernelGGL((k_scan_half<1, true>), dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
+      else if (wide_teams)
+        hipLaunchKernelGGL((k_scan_half<1, false, SMX_TEAM>), dim3(wide_blocks), dim3(SMX_BLOCK), 0, stream, k);
       else
         hipLaunchKernelGGL(k_scan_half<1>, dim3(half_blocks), dim3(SMX_BLOCK), 0, stream, k);
       // the facts half (-> observe) has slack, the seeds half heads the tick's longest chain (-> walk -> rows): the
@@ -5564,7 +5575,9 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       if (fast) {
         hipLaunchKernelGGL(k_scan_fast<0>, dim3(fast_blocks), dim3(SMX_BLOCK), 0, s_obs, kf);
         hipLaunchKernelGGL(k_scan_listed<0>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, s_obs, kf);
-      } else
+      } else if (wide_teams)
+        hipLaunchKernelGGL((k_scan_half<0, false, SMX_TEAM>), dim3(wide_blocks), dim3(SMX_BLOCK), 0, s_obs, k);
+      else
         hipLaunchKernelGGL(k_scan_half<0>, dim3(half_blocks), dim3(SMX_BLOCK), 0, s_obs, k);  // (the facts half seeds no path)
       // (holding the grid kernels back as well was slower: 0.81 -> 0.85 ms; they overlap the seeds half)
     } else if (scan_split) {
