@@ -838,19 +838,22 @@ __device__ __forceinline__ void control_paths_for(const KernelArgs& a, const Ctr
 
 // One team of four lanes per vehicle.  With a slow list in the arguments (large batches: the vehicles k_control_fast
 // could not serve) a fixed grid strides that list, whose length is only known on the device.
+// (the list form is a kernel of its own: with both forms in one kernel the role was inlined twice and the team cut's
+// launch paid for it — 111 -> 137 registers here, 168 -> 256 in k_control_law, one wavefront per SIMD: C5's control
+// phase 0.169 -> 0.209 ms)
 template <int SPACE>
 __global__ void __launch_bounds__(SMX_BLOCK) k_control_paths(const KernelArgs a, const CtrlHandoff ho) {
   __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
-  int* knots = knot_scratch + threadIdx.x;
   const size_t total = (size_t)a.cfg.num_envs * a.cfg.num_vehicles;
+  control_paths_for<SPACE>(a, ho, launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, total), knot_scratch + threadIdx.x);
+}
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_paths_listed(const KernelArgs a, const CtrlHandoff ho) {
+  __shared__ int knot_scratch[SMX_MAX_KNOTS * SMX_BLOCK];
   constexpr int VPB = SMX_BLOCK / SMX_WP_LANES;
-  if (a.slow_list != nullptr) {
-    const int count = *a.slow_count;
-    for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
-      control_paths_for<SPACE>(a, ho, (size_t)a.slow_list[i], knots);
-    return;
-  }
-  control_paths_for<SPACE>(a, ho, launch_vehicle(a, ((size_t)blockIdx.x * SMX_BLOCK + threadIdx.x) / SMX_WP_LANES, total), knots);
+  const int count = *a.slow_count;
+  for (int i = (int)blockIdx.x * VPB + (int)threadIdx.x / SMX_WP_LANES; i < count; i += (int)gridDim.x * VPB)
+    control_paths_for<SPACE>(a, ho, (size_t)a.slow_list[i], knot_scratch + threadIdx.x);
 }
 
 // Control law + vehicle dynamics, one lane per vehicle (see k_control_paths).  Every action space; the
@@ -966,13 +969,13 @@ __device__ __forceinline__ void control_law_for(const KernelArgs& a, const CtrlH
 
 template <int SPACE>
 __global__ void __launch_bounds__(SMX_BLOCK) k_control_law(const KernelArgs a, const CtrlHandoff ho) {
-  if (a.slow_list != nullptr) {  // the vehicles k_control_fast left to k_control_paths (see there)
-    const int count = *a.slow_count;
-    for (int i = (int)blockIdx.x * SMX_BLOCK + (int)threadIdx.x; i < count; i += (int)gridDim.x * SMX_BLOCK)
-      control_law_for<SPACE>(a, ho, (size_t)a.slow_list[i]);
-    return;
-  }
   control_law_for<SPACE>(a, ho, (size_t)blockIdx.x * SMX_BLOCK + threadIdx.x);
+}
+template <int SPACE>
+__global__ void __launch_bounds__(SMX_BLOCK) k_control_law_listed(const KernelArgs a, const CtrlHandoff ho) {
+  const int count = *a.slow_count;  // the vehicles k_control_fast left to k_control_paths_listed (see there)
+  for (int i = (int)blockIdx.x * SMX_BLOCK + (int)threadIdx.x; i < count; i += (int)gridDim.x * SMX_BLOCK)
+    control_law_for<SPACE>(a, ho, (size_t)a.slow_list[i]);
 }
 
 // =================================================================================
@@ -5676,8 +5679,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       case SMX_ACTION_SPACE_LANE:
         if (fast_scan && h->slow_blob) {  // one lane per vehicle; the rest through the slow list (k_control_fast)
           hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
-          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
-          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_paths_listed<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law_listed<SMX_ACTION_SPACE_LANE>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
         } else {
           hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
           hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
@@ -5686,8 +5689,8 @@ static int enqueue(smx_handle h, bool is_step, const int8_t* actions, const floa
       case SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED:
         if (fast_scan && h->slow_blob) {
           hipLaunchKernelGGL(k_control_fast<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, ac);
-          hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
-          hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_paths_listed<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
+          hipLaunchKernelGGL(k_control_law_listed<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3((unsigned)h->slow_blocks), dim3(SMX_BLOCK), 0, stream, ac, ho);
         } else {
           hipLaunchKernelGGL(k_control_paths<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(wp_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
           hipLaunchKernelGGL(k_control_law<SMX_ACTION_SPACE_LANE_WITH_CONTINUOUS_SPEED>, dim3(veh_blocks), dim3(SMX_BLOCK), 0, stream, a, ho);
