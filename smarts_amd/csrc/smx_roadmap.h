@@ -300,7 +300,7 @@ struct RouteFilter {
     if (n == SMX_ROUTE_FIXED) return m.route_pos[road[0] * m.n_roads + r] >= 0;
     return (n > 0 && road[0] == r) || (n > 1 && road[1] == r);
   }
-  __device__ __forceinline__ int last() const { return n == SMX_ROUTE_FIXED ? road[1] : road[n - 1]; }
+  __device__ __forceinline__ int last() const { return (n == SMX_ROUTE_FIXED || n == 2) ? road[1] : road[0]; }  // (n = 1, 2: road[n - 1])
   __device__ __forceinline__ void none() {
     n = 0;
     road[0] = road[1] = -1;
@@ -977,8 +977,10 @@ __device__ inline PathSeeds compute_path_seeds(const MapDev& m, double px, doubl
 // Start lanepoint on lane number `li` (position within the road) of the seed road.
 __device__ __forceinline__ int seed_start(const MapDev& m, const PathSeeds& s, int li, double px, double py) {
   if (li < SMX_SEED_LANES) {
-    // static selection keeps the array in registers
-    return li == 0 ? s.start[0] : (li == 1 ? s.start[1] : (li == 2 ? s.start[2] : s.start[3]));
+    // a tree of selects on the index's bits keeps the array in registers (an indexed read, and this compiler's rewrite of
+    // a chain of equality selects into one, put the whole PathSeeds into scratch memory: 40 B a lane in every walk kernel)
+    const int lo = (li & 1) ? s.start[1] : s.start[0], hi = (li & 1) ? s.start[3] : s.start[2];
+    return (li & 2) ? hi : lo;
   }
   int key[4] = {m.road_lanes[m.road_lane_off[s.road] + li], -9, -9, -9};
   int idx[4];

@@ -917,35 +917,35 @@ __device__ inline double team_lane_heading_at_point(const MapDev& m, int lane, d
 // case (both offsets within four segments of vfrom); otherwise the walk of team_position_at_shape_offset.
 __device__ inline void lane_positions_at_offsets(const MapDev& m, int v0, int v1, int vfrom, double s_off, double e_off,
                                                  double& p1x, double& p1y, double& p2x, double& p2y) {
-  smx_shape_rec r[5];
-#pragma unroll
-  for (int u = 0; u < 5; ++u) r[u] = m.shape_rec[min(vfrom + u, v1 - 1)];
-  int hs = -1, he = -1;
-#pragma unroll
-  for (int u = 3; u >= 0; --u) {
-    const bool seg = vfrom + u + 1 < v1;  // vertex vfrom + u starts a segment
-    if (seg && r[u].cum + r[u].len > s_off) hs = u;
-    if (seg && r[u].cum + r[u].len > e_off) he = u;
-  }
-  // (the first hit: a later iteration of the descending loop overwrites a later hit with an earlier one)
-  auto at = [&](int u, double off, double& ox, double& oy) {
-    // (selects, not an indexed copy of the records: that would live in scratch memory)
-    const double ax = u == 0 ? r[0].x : (u == 1 ? r[1].x : (u == 2 ? r[2].x : r[3].x));
-    const double ay = u == 0 ? r[0].y : (u == 1 ? r[1].y : (u == 2 ? r[2].y : r[3].y));
-    const double al = u == 0 ? r[0].len : (u == 1 ? r[1].len : (u == 2 ? r[2].len : r[3].len));
-    const double ac = u == 0 ? r[0].cum : (u == 1 ? r[1].cum : (u == 2 ? r[2].cum : r[3].cum));
-    const double bx = u == 0 ? r[1].x : (u == 1 ? r[2].x : (u == 2 ? r[3].x : r[4].x));
-    const double by = u == 0 ? r[1].y : (u == 1 ? r[2].y : (u == 2 ? r[3].y : r[4].y));
-    position_at_offset(ax, ay, bx, by, al, off - ac, ox, oy);
+  // (named scalars, not an array of records: the compiler kept the array in scratch memory — 176 B a lane — and
+  // turned the selects below into selected scratch addresses, a memory round trip in front of each position)
+  const smx_shape_rec q0 = m.shape_rec[min(vfrom + 0, v1 - 1)], q1 = m.shape_rec[min(vfrom + 1, v1 - 1)],
+                      q2 = m.shape_rec[min(vfrom + 2, v1 - 1)], q3 = m.shape_rec[min(vfrom + 3, v1 - 1)],
+                      q4 = m.shape_rec[min(vfrom + 4, v1 - 1)];
+  const double x0 = q0.x, x1 = q1.x, x2 = q2.x, x3 = q3.x, x4 = q4.x;
+  const double y0 = q0.y, y1 = q1.y, y2 = q2.y, y3 = q3.y, y4 = q4.y;
+  const double l0 = q0.len, l1 = q1.len, l2 = q2.len, l3 = q3.len;
+  const double c0 = q0.cum, c1 = q1.cum, c2 = q2.cum, c3 = q3.cum;
+  // The first segment (ascending) whose end lies beyond the offset: evaluated in descending order, every hit
+  // overwriting the later ones — no index into the records, which the compiler would serve from a table in scratch
+  // memory (it did: a store and a dependent load in front of each position).
+  bool fs = false, fe = false;
+  auto seg_at = [&](bool seg, double ax, double ay, double bx, double by, double al, double ac) {
+    if (seg && ac + al > s_off) {
+      position_at_offset(ax, ay, bx, by, al, s_off - ac, p1x, p1y);
+      fs = true;
+    }
+    if (seg && ac + al > e_off) {
+      position_at_offset(ax, ay, bx, by, al, e_off - ac, p2x, p2y);
+      fe = true;
+    }
   };
-  if (hs >= 0)
-    at(hs, s_off, p1x, p1y);
-  else
-    team_position_at_shape_offset<1>(m, v0, v1, s_off, p1x, p1y, vfrom);
-  if (he >= 0)
-    at(he, e_off, p2x, p2y);
-  else
-    team_position_at_shape_offset<1>(m, v0, v1, e_off, p2x, p2y, vfrom);
+  seg_at(vfrom + 4 < v1, x3, y3, x4, y4, l3, c3);
+  seg_at(vfrom + 3 < v1, x2, y2, x3, y3, l2, c2);
+  seg_at(vfrom + 2 < v1, x1, y1, x2, y2, l1, c1);
+  seg_at(vfrom + 1 < v1, x0, y0, x1, y1, l0, c0);
+  if (!fs) team_position_at_shape_offset<1>(m, v0, v1, s_off, p1x, p1y, vfrom);
+  if (!fe) team_position_at_shape_offset<1>(m, v0, v1, e_off, p2x, p2y, vfrom);
 }
 
 // `cand`: this lane's column of an LDS array [SMX_FACTS_CAND][stride] of record indices.
